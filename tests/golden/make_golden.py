@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE ITSELF (imported from /root/reference, build container only).
+
+The reference's Python never travels to the GPU box; only the small .npz fixtures written here do.
+Weights and inputs are regenerated from seeds by vtamiq_amd.synth (our own generator), loaded into the
+reference modules through load_state_dict with the reference's key names, and the reference's outputs
+are stored.  Absent third-party modules are stubbed in sys.modules (public-API semantics only):
+  timm.layers.DropPath / timm.models.layers.{DropPath, trunc_normal_}  (identity in eval)
+  cv2, imageio, torchvision, tensorboardX, skimage                       (import-time only, for train.py)
+
+Run:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("VTAMIQ_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from vtamiq_amd import synth                      # noqa: E402
+from vtamiq_amd.spec import make_spec             # noqa: E402
+
+
+def _install_stubs():
+    class DropPath(torch.nn.Module):               # timm public API: identity unless training with p>0
+        def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+            super().__init__()
+            self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+        def forward(self, x):
+            if self.drop_prob == 0. or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            if keep > 0. and self.scale_by_keep:
+                m.div_(keep)
+            return x * m
+
+    timm = types.ModuleType("timm")
+    timm.layers = types.ModuleType("timm.layers")
+    timm.models = types.ModuleType("timm.models")
+    timm.models.layers = types.ModuleType("timm.models.layers")
+    timm.layers.DropPath = DropPath
+    timm.models.layers.DropPath = DropPath
+    timm.models.layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    for n, m in (("timm", timm), ("timm.layers", timm.layers), ("timm.models", timm.models),
+                 ("timm.models.layers", timm.models.layers)):
+        sys.modules[n] = m
+
+
+def _install_train_stubs():
+    """Import-time stubs so that train.py / train_config.py import."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Err(Exception):
+        pass
+    mod("cv2", error=_Err)
+    mod("imageio")
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms")
+    tv.transforms.functional = mod("torchvision.transforms.functional")
+    tv.models = mod("torchvision.models", VGG16_Weights=object, vgg16=None)
+    mod("tensorboardX", SummaryWriter=object)
+    sk = mod("skimage")
+    sk.util = mod("skimage.util")
+    sk.util.shape = mod("skimage.util.shape", view_as_windows=None)
+    mod("thop", profile=None)
+
+
+def build_reference(vtamiq_kwargs):
+    from modules.vtamiq.vtamiq import VTAMIQ       # reference import
+    kw = json.loads(json.dumps(vtamiq_kwargs))     # deep copy (the ctor pops keys)
+    kw.setdefault("vit_config", {})["pretrained"] = False
+    model = VTAMIQ(**kw)
+    model.eval()
+    return model
+
+
+def load_seeded(model, spec, seed):
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec, seed).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return sd
+
+
+def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False):
+    kw = json.loads(json.dumps(vtamiq_kwargs))
+    spec = make_spec(**json.loads(json.dumps(kw)))
+    if trace:
+        kw.setdefault("vit_config", {})["return_layers"] = True
+    model = build_reference(kw)
+    ref_keys = sorted(model.state_dict().keys())
+    our_keys = sorted(k for k, _, _ in spec.state_layout())
+    assert ref_keys == our_keys, (set(ref_keys) ^ set(our_keys))
+    for k, shape, _ in spec.state_layout():
+        assert tuple(model.state_dict()[k].shape) == tuple(shape), (k, shape)
+    load_seeded(model, spec, wseed)
+    patches, pos, scales = synth.make_inputs(spec, B, N, iseed, aligned=aligned)
+    tp, tpos = torch.from_numpy(patches), torch.from_numpy(pos)
+    p = (tp[:, 0].clone(), tp[:, 1].clone())
+    ps = (tpos[:, 0].clone(), tpos[:, 1].clone())
+    if scales is not None:
+        ts = torch.from_numpy(scales).to(torch.float32)     # train.py:254-255 casts scales to f32
+        sc = (ts[:, 0].clone(), ts[:, 1].clone())
+    else:
+        sc = (None, None)
+    out = dict(kwargs=json.dumps(vtamiq_kwargs), B=B, N=N, wseed=wseed, iseed=iseed, aligned=int(aligned))
+    with torch.no_grad():
+        q, aux = model(p, ps, sc)
+        assert aux is None
+        out["q"] = q.numpy().astype(np.float32)
+        if trace:
+            for side, (pp, pq, s_) in (("ref", (p[0], ps[0], sc[0])), ("dist", (p[1], ps[1], sc[1]))):
+                x, _, hidden = model.forward_vit(pp, pq, s_, tokens_only=True)
+                out[f"tokens_{side}"] = torch.stack(hidden).numpy().astype(np.float32)   # (L,B,T,H), pre final LN
+                out[f"final_{side}"] = x.numpy().astype(np.float32)                      # (B,T,H), after encoder_norm
+    # fingerprints of the regenerated tensors, to detect generator drift
+    out["fp_patches"] = np.float64(patches.astype(np.float64).sum())
+    out["fp_pos"] = np.float64(pos.astype(np.float64).sum())
+    sdnp = synth.make_state_dict(spec, wseed)
+    out["fp_weights"] = np.float64(sum(float(v.astype(np.float64).sum()) for v in sdnp.values()))
+    np.savez(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: q={out['q']}")
+
+
+def run_ops():
+    """Toy-size per-op fixtures with full weights committed."""
+    from modules.VisionTransformer import transformer as T
+    from modules.RCAN.channel_attention import RCAB, ResidualGroup, CALayer
+    g = torch.Generator().manual_seed(7)
+    out = {}
+
+    def rnd(*s, scale=1.0):
+        return torch.randn(*s, generator=g) * scale
+
+    def randomize(m, scale=0.1):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(rnd(*p.shape, scale=scale) + (1.0 if p.ndim == 1 and p.numel() > 1 and False else 0.0))
+
+    def dump(prefix, m):
+        for k, v in m.state_dict().items():
+            out[f"{prefix}/sd/{k}"] = v.numpy()
+
+    cfg = {"num_heads": 4, "hidden_size": 64, "mlp_dim": 128, "patch_size": 16, "img_dim": 64}
+    with torch.no_grad():
+        m = T.MultiHeadSelfAttention(cfg, 1).eval(); randomize(m)
+        x = rnd(2, 11, 64)
+        y, w = m(x)
+        dump("mhsa", m); out["mhsa/x"], out["mhsa/y"], out["mhsa/probs"] = x.numpy(), y.numpy(), w.numpy()
+
+        m = T.MLP(cfg).eval(); randomize(m)
+        y = m(x)
+        dump("mlp", m); out["mlp/x"], out["mlp/y"] = x.numpy(), y.numpy()
+
+        m = T.EncoderLayer(cfg, True, 0, 1, 0.1).eval(); randomize(m)
+        y, _ = m(x)
+        dump("layer", m); out["layer/x"], out["layer/y"] = x.numpy(), y.numpy()
+
+        m = T.Embeddings(cfg, True, True, True, 2, 3).eval(); randomize(m)
+        pt = rnd(2, 5, 3, 16, 16)
+        pos = torch.rand(2, 5, 2, generator=g).clamp(max=1 - 1e-6)
+        sc = torch.tensor([[0., 1., 2., 5., -1.], [2., 2., 0., 1., 1.]])
+        y = m(pt, pos, sc)
+        dump("emb", m)
+        out["emb/patches"], out["emb/pos"], out["emb/scales"], out["emb/y"] = pt.numpy(), pos.numpy(), sc.numpy(), y.numpy()
+
+        m = T.UvPosEmbedding({"hidden_size": 8, "patch_size": 16, "img_dim": 384}).eval(); randomize(m)
+        pos = torch.tensor([[0., 0.], [0.999999, 0.999999], [0.5, 0.25], [1 / 24., 23 / 24.], [0.0416, 0.9584]])
+        out["uvpos/pos"], out["uvpos/y"] = pos.numpy(), m(pos).numpy()
+        dump("uvpos", m)
+
+        m = RCAB(64, 8, use_bn=False, input1d=True).eval(); randomize(m)
+        x1 = rnd(3, 64, 1)
+        dump("rcab", m); out["rcab/x"], out["rcab/y"] = x1.numpy(), m(x1).numpy()
+
+        m = ResidualGroup(64, 2, reduction=8, path_drop_prob=0.1, use_bn=False, input1d=True).eval(); randomize(m)
+        dump("rg", m); out["rg/x"], out["rg/y"] = x1.numpy(), m(x1).numpy()
+    np.savez(os.path.join(HERE, "ops_toy.npz"), **out)
+    print("ops_toy: ", len(out), "arrays")
+
+
+def run_plumbing():
+    """BASELINE config 1 'forward via train.py': get_data_tuple -> predict (non-pairwise).  train.py:254-314."""
+    _install_train_stubs()
+    import train as ref_train
+    kw = dict(vit_config=dict(variant="ViT-B16"))
+    spec = make_spec(**json.loads(json.dumps(kw)))
+    model = build_reference(kw)
+    load_seeded(model, spec, 3)
+    B, N = 2, 50
+    patches, pos, _ = synth.make_inputs(spec, B, N, 77)
+    q_true = np.array([0.25, 0.75], dtype=np.float64)
+    scales = np.full((B,), -1, dtype=np.int32)                     # single-scale loader output (patch_datasets.py)
+    batch = (torch.from_numpy(q_true), torch.from_numpy(patches), torch.from_numpy(pos), torch.from_numpy(scales))
+    with torch.no_grad():
+        data = ref_train.get_data_tuple(batch, torch.device("cpu"))
+        q, q_p, feats = ref_train.predict(model, None, data, False, False, False)
+    assert feats is None
+    np.savez(os.path.join(HERE, "plumbing_c1.npz"), kwargs=json.dumps(kw), B=B, N=N, wseed=3, iseed=77,
+             q_in=q_true, q=q.numpy(), q_p=q_p.numpy().astype(np.float32))
+    print("plumbing_c1:", q.numpy(), q_p.numpy())
+
+
+def main():
+    sys.path.insert(0, REF)
+    _install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    B16 = "ViT-B16"
+    run_case("c1_b2_n50", dict(vit_config=dict(variant=B16)), B=2, N=50, wseed=1, iseed=11, trace=True)
+    run_case("refdefault_b2_n64",
+             dict(vit_config=dict(variant=B16, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True,
+                                  path_drop_prob=0.1, num_scales=0),
+                  ca_reduction=16, rg_path_drop=0.1, predictor_dropout=0.1), B=2, N=64, wseed=2, iseed=12)
+    run_case("scales3_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, num_scales=3, num_extra_tokens=2)),
+             B=2, N=40, wseed=3, iseed=13)
+    run_case("unaligned_b3_n50", dict(vit_config=dict(variant=B16, num_keep_layers=3)), B=3, N=50, wseed=4, iseed=14,
+             aligned=False)
+    run_case("c2shape_b4_n500", dict(vit_config=dict(variant=B16)), B=4, N=500, wseed=5, iseed=15)
+    run_case("vitl_b2_n70", dict(vit_config=dict(variant="ViT-L16", num_keep_layers=2, num_scales=3)),
+             B=2, N=70, wseed=6, iseed=16)
+    run_case("nocalib_b2_n30", dict(vit_config=dict(variant=B16, num_keep_layers=1), calibrate=False, diff_scale=False),
+             B=2, N=30, wseed=7, iseed=17)
+    run_ops()
+    run_plumbing()
+
+
+if __name__ == "__main__":
+    main()

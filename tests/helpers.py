@@ -1,0 +1,53 @@
+"""Shared test helpers (CPU side)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from vtamiq_amd import synth
+from vtamiq_amd.spec import make_spec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+E2E_CASES = ["c1_b2_n50", "refdefault_b2_n64", "scales3_b2_n40", "unaligned_b3_n50", "c2shape_b4_n500",
+             "vitl_b2_n70", "nocalib_b2_n30"]
+
+
+def load_case(name):
+    """-> (golden npz dict, vtamiq kwargs, spec, numpy state dict, (patches, pos, scales) numpy)."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    kw = json.loads(str(g["kwargs"]))
+    spec = make_spec(**json.loads(json.dumps(kw)))
+    sd = synth.make_state_dict(spec, int(g["wseed"]))
+    patches, pos, scales = synth.make_inputs(spec, int(g["B"]), int(g["N"]), int(g["iseed"]),
+                                             aligned=bool(int(g.get("aligned", 1))))
+    # generator drift guard: the fixtures were produced from exactly these tensors
+    assert abs(float(patches.astype(np.float64).sum()) - float(g["fp_patches"])) < 1e-6
+    assert abs(float(pos.astype(np.float64).sum()) - float(g["fp_pos"])) < 1e-6
+    assert abs(sum(float(v.astype(np.float64).sum()) for v in sd.values()) - float(g["fp_weights"])) < 1e-6
+    return g, kw, spec, sd, (patches, pos, scales)
+
+
+def split_inputs(patches, pos, scales, device="cpu", dtype=torch.float32):
+    """Collated [B,2,...] numpy -> the ((ref,dist),(pos_ref,pos_dist),(sc_ref,sc_dist)) call tuple (train.py:304-306)."""
+    tp = torch.from_numpy(patches).to(device=device, dtype=dtype)
+    tq = torch.from_numpy(pos).to(device=device, dtype=dtype)
+    p = (tp[:, 0].clone(), tp[:, 1].clone())
+    ps = (tq[:, 0].clone(), tq[:, 1].clone())
+    if scales is not None:
+        ts = torch.from_numpy(scales).to(device=device, dtype=dtype)
+        sc = (ts[:, 0].clone(), ts[:, 1].clone())
+    else:
+        sc = (None, None)
+    return p, ps, sc
+
+
+def rel_err(q, q_ref):
+    """Parity metrics of SURVEY 8(d): raw per-element relative, rms-normalised, absolute."""
+    q = np.asarray(q, dtype=np.float64)
+    q_ref = np.asarray(q_ref, dtype=np.float64)
+    d = np.abs(q - q_ref)
+    rms = float(np.sqrt(np.mean(q_ref ** 2)))
+    return dict(max_rel=float(np.max(d / np.abs(q_ref))), med_rel=float(np.median(d / np.abs(q_ref))),
+                max_abs=float(d.max()), max_rel_rms=float(d.max() / rms), rms=rms)

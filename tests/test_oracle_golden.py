@@ -1,0 +1,106 @@
+"""Pin the oracle (CPU restatement) against golden vectors captured from the imported reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vtamiq_oracle as O
+from tests.helpers import E2E_CASES, GOLDEN, load_case, split_inputs, rel_err
+import os
+
+# fp32 op-order differences between the restatement and the reference modules stay below this
+ORACLE_RTOL = 2e-5
+
+
+@pytest.mark.parametrize("name", E2E_CASES)
+def test_e2e_q(name):
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales)
+    q, aux = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)
+    assert aux is None and q.shape == (int(g["B"]),) and q.dtype == torch.float32
+    e = rel_err(q.numpy(), g["q"])
+    assert e["max_rel_rms"] < ORACLE_RTOL, e
+    assert e["max_abs"] < 1e-6, e
+
+
+def test_per_layer_tokens_c1():
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    p, ps, sc = split_inputs(patches, pos, scales)
+    trace = {}
+    O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc, trace=trace)
+    for side in ("ref", "dist"):
+        got = trace[f"tokens_{side}"][1:].numpy()          # entry 0 is the embedding output
+        want = g[f"tokens_{side}"]                         # (L,B,T,H) pre final LN, return_layers=True
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+
+
+def _sub(ops, prefix):
+    return {k[len(prefix) + 4:]: torch.from_numpy(v) for k, v in ops.items() if k.startswith(prefix + "/sd/")}
+
+
+def test_toy_ops():
+    ops = dict(np.load(os.path.join(GOLDEN, "ops_toy.npz")))
+    T = lambda k: torch.from_numpy(ops[k])
+    # attention (transformer.py:153-172) incl. the returned probabilities
+    sd = {"L.attn." + k: v for k, v in _sub(ops, "mhsa").items()}
+    y, probs = O.attention(sd, "L.", T("mhsa/x"), 4, return_probs=True)
+    np.testing.assert_allclose(y.numpy(), ops["mhsa/y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(probs.numpy(), ops["mhsa/probs"], rtol=1e-5, atol=1e-7)
+    # MLP with exact-erf GELU
+    sd = {"L.ffn." + k: v for k, v in _sub(ops, "mlp").items()}
+    np.testing.assert_allclose(O.mlp(sd, "L.", T("mlp/x")).numpy(), ops["mlp/y"], rtol=1e-5, atol=1e-6)
+
+    # full encoder layer with LayerScale
+    class S:  # minimal spec view
+        num_heads, use_layer_scale = 4, True
+    sd = {"transformer.encoder.layers.0." + k: v for k, v in _sub(ops, "layer").items()}
+    np.testing.assert_allclose(O.encoder_layer(sd, S, 0, T("layer/x")).numpy(), ops["layer/y"], rtol=1e-5, atol=1e-6)
+
+    # embeddings: patch conv + pos gather + scale gather (clamped) + CLS(+pos[0]) + 2 register tokens
+    class E:
+        pos_grid, num_scales, use_scale_embedding, num_extra_tokens = 4, 3, True, 2
+    sd = {"transformer.embeddings." + k: v for k, v in _sub(ops, "emb").items()}
+    y = O.embeddings(sd, E, T("emb/patches"), T("emb/pos"), T("emb/scales"))
+    np.testing.assert_allclose(y.numpy(), ops["emb/y"], rtol=1e-5, atol=5e-6)   # conv vs GEMM summation order, K=768
+    # uv position index edge cases (0, 1-1e-6, exact cell borders)
+    table = torch.from_numpy(ops["uvpos/sd/positional_embeddings"])[0]
+    got = table[O.pos_index(T("uvpos/pos"), 24)]
+    np.testing.assert_array_equal(got.numpy(), ops["uvpos/y"][0])
+    # RCAB / ResidualGroup on (B,C,1)
+    sd = {"R." + k: v for k, v in _sub(ops, "rcab").items()}
+    np.testing.assert_allclose(O.rcab(sd, "R.", T("rcab/x")[..., 0]).numpy(), ops["rcab/y"][..., 0], rtol=1e-5, atol=1e-6)
+
+    class G:
+        calibrate, num_rgs, num_rcabs = True, 1, 2
+    sd = {"quality_decoder.0." + k: v for k, v in _sub(ops, "rg").items()}
+    x = T("rg/x")[..., 0]
+    y = x
+    for k in range(2):
+        y = O.rcab(sd, f"quality_decoder.0.body.{k}.", y)
+    y = x + O._conv1x1(sd, "quality_decoder.0.body.2", y)
+    np.testing.assert_allclose(y.numpy(), ops["rg/y"][..., 0], rtol=1e-5, atol=1e-6)
+
+
+def test_plumbing_c1():
+    """BASELINE config 1: collated batch -> f32 cast -> per-image split -> model -> (q, q_p)."""
+    import json
+    from vtamiq_amd import synth
+    from vtamiq_amd.spec import make_spec
+    g = dict(np.load(os.path.join(GOLDEN, "plumbing_c1.npz")))
+    spec = make_spec(**json.loads(str(g["kwargs"])))
+    sd = O.to_torch(synth.make_state_dict(spec, int(g["wseed"])))
+    patches, pos, _ = synth.make_inputs(spec, int(g["B"]), int(g["N"]), int(g["iseed"]))
+    batch = (g["q_in"], patches, pos, np.full((int(g["B"]),), -1, dtype=np.int32))
+    q, q_p = O.predict(sd, spec, batch)
+    assert q.dtype == torch.float32 and q_p.shape == (2,)
+    np.testing.assert_array_equal(q.numpy(), g["q"])
+    assert rel_err(q_p.numpy(), g["q_p"])["max_rel_rms"] < ORACLE_RTOL
+
+
+def test_fp64_agrees():
+    """fp32 oracle vs the same restatement in fp64: the fp32 noise floor that bounds any parity claim."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    p, ps, sc = split_inputs(patches, pos, scales, dtype=torch.float64)
+    q64, _ = O.vtamiq_forward(O.to_torch(sd, torch.float64), spec, p, ps, sc)
+    e = rel_err(g["q"], q64.numpy())
+    assert e["max_rel_rms"] < 1e-4, e
