@@ -1,0 +1,132 @@
+/*
+ * vtamiq_hip.h -- C ABI of libvtamiq_hip.so, the MI355X (gfx950) engine for VTAMIQ's ViT patch-pair forward.
+ *
+ * The reference (ch-andrei/VTAMIQ) is pure Python/PyTorch and has no FFI of its own; this header is the
+ * boundary a maintainer binds with ctypes.  Each entry point names the reference code
+ * it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller (torch) owns all inputs/outputs,
+ *     the library owns only packed weights and its workspace;
+ *   - all calls are asynchronous on the hipStream_t passed in (void* here so the header needs no HIP include);
+ *     no internal synchronisation except where stated;
+ *   - int return: 0 = ok, non-zero = error; text via vtq_last_error(); no exceptions cross the ABI;
+ *   - a handle is not thread-safe; one process per GPU.
+ */
+#ifndef VTAMIQ_HIP_H
+#define VTAMIQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTQ_ABI_VERSION 1
+
+/* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in both) */
+#define VTQ_PREC_BF16   0   /* one bf16 MFMA per product: the throughput mode                          */
+#define VTQ_PREC_BF16X3 1   /* operands split hi+lo bf16, hi*hi + lo*hi + hi*lo: meets 1e-3 vs fp32 CPU */
+
+typedef struct vtq_config {
+    int32_t hidden_size;       /* 768 | 1024                (transformer.py:68-98)                    */
+    int32_t mlp_dim;           /* 3072 | 4096                                                         */
+    int32_t num_heads;         /* 12 | 16 ; head_dim must be 64                                       */
+    int32_t num_layers;        /* kept layers               (transformer.py:342-345)                  */
+    int32_t patch_dim;         /* 3*16*16 = 768                                                       */
+    int32_t pos_grid;          /* 24                        (transformer.py:411)                      */
+    int32_t num_extra_tokens;  /* register tokens           (transformer.py:487-492)                  */
+    int32_t num_scales;        /* scale embedding iff > 1   (transformer.py:500)                      */
+    int32_t use_layer_scale;   /* ls1/ls2 gamma             (transformer.py:270-271)                  */
+    int32_t calibrate;         /* DiffNet on/off            (vtamiq.py:63-69)                         */
+    int32_t diff_scale;        /* LayerScale on the CLS diff (vtamiq.py:61)                           */
+    int32_t num_rgs;           /* vtamiq.py:34                                                        */
+    int32_t num_rcabs;         /* vtamiq.py:35                                                        */
+    int32_t ca_hidden;         /* hidden_size / ca_reduction (channel_attention.py:75)                */
+    int32_t precision;         /* VTQ_PREC_*                                                          */
+    int32_t reserved[5];
+} vtq_config;
+
+typedef struct vtq_tensor_desc {
+    const char*  name;         /* HOST string: the reference's state_dict key          */
+    const float* data;         /* DEVICE pointer, fp32, contiguous                                    */
+    int64_t      numel;
+} vtq_tensor_desc;
+
+typedef struct vtq_engine* vtq_handle;
+
+int         vtq_abi_version(void);
+const char* vtq_last_error(void);
+
+/* Replaces VTAMIQ.__init__ / VisionTransformer.__init__ for the inference path (vtamiq.py:27-79). */
+int  vtq_create(const vtq_config* cfg, vtq_handle* out);
+void vtq_destroy(vtq_handle h);
+
+/* Replaces Module.load_state_dict for the engine: borrows fp32 device tensors for the duration of the call
+ * (which synchronises the stream before returning) and packs them to bf16 (hi[,lo]) / fp32 buffers owned by
+ * the handle.  Unknown names are an error; every tensor of the configured topology must be present. */
+int  vtq_load_weights(vtq_handle h, const vtq_tensor_desc* descs, int32_t n, void* stream);
+
+/* Bytes of device workspace the handle holds for a (B pairs, N patches) call. */
+size_t vtq_workspace_bytes(vtq_handle h, int32_t B, int32_t N);
+/* Grows the workspace ahead of time (hipMalloc happens here, or lazily on the first larger vtq_forward). */
+int  vtq_reserve(vtq_handle h, int32_t B, int32_t N);
+
+/* Replaces VTAMIQ.forward (vtamiq.py:94-119): q_out[B] = score of each (ref, dist) pair.
+ *   patches_* : [B, N, 3, 16, 16] fp32 contiguous      pos_* : [B, N, 2] fp32 in [0,1)
+ *   scales_*  : [B, N] fp32-cast scale ids, or NULL when the model has no scale embedding
+ *               (NULL with num_scales > 1 is an error, as in transformer.py:547-548). */
+int  vtq_forward(vtq_handle h,
+                 const float* patches_ref, const float* patches_dist,
+                 const float* pos_ref, const float* pos_dist,
+                 const float* scales_ref, const float* scales_dist,
+                 int32_t B, int32_t N, float* q_out, void* stream);
+
+/* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
+ * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors
+ * vit_config["return_layers"] (transformer.py:369-372, 632-636). */
+int  vtq_set_token_trace(vtq_handle h, float* buf);
+
+/* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
+#define VTQ_K_CONVERT  0
+#define VTQ_K_PATCH    1   /* patch-embedding GEMM + pos/scale gather epilogue */
+#define VTQ_K_LN       2
+#define VTQ_K_QKV      3
+#define VTQ_K_ATTN     4
+#define VTQ_K_OUTPROJ  5
+#define VTQ_K_FC1      6
+#define VTQ_K_FC2      7
+#define VTQ_K_HEAD     8
+#define VTQ_K_COUNT    9
+/* mask: bit k set = bracket every launch of class k with hipEvents (0 disables). */
+int  vtq_profile_enable(vtq_handle h, uint32_t class_mask);
+/* Synchronises the recorded events; ms_sum[k], launches[k] for k < VTQ_K_COUNT (HOST arrays); resets. */
+int  vtq_profile_collect(vtq_handle h, double* ms_sum, int64_t* launches);
+
+/* ---- per-kernel entry points (unit tests call these through the same ABI) ----------------------------- */
+/* fp32 [rows, cols] -> bf16 planes: dst (hi) and, when nsplit == 3, dst + plane_stride (lo). */
+int  vtq_k_split_bf16(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t nsplit, void* stream);
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+epilogue); A/W are bf16 planes as above; M%256==0, N%256==0, K%64==0.
+ *   epilogue 0: out_bf16 = acc + bias
+ *            1: out_bf16 = gelu_erf(acc + bias)                            (transformer.py:212-215)
+ *            2: x_f32   += gamma * (acc + bias)   (gamma NULL = 1)         (transformer.py:279,284) */
+int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane,
+                int32_t M, int32_t N, int32_t K, int32_t nsplit, int32_t epilogue,
+                const float* bias, const float* gamma, float* x_f32,
+                void* out_bf16, int64_t o_plane, int32_t ldo, void* stream);
+
+/* LayerNorm(eps=1e-6) rows of x[rows, H] fp32 -> bf16 planes (transformer.py:253-254, 276, 281). */
+int  vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane,
+                     int32_t rows, int32_t H, int32_t nsplit, void* stream);
+
+/* softmax(Q K^T / sqrt(64)) V per (sequence, head) on the packed qkv[rows, 3H] bf16 planes; sequences are
+ * S_pad rows apart, keys >= S are masked; out[rows, H] bf16 planes, heads merged (transformer.py:153-166). */
+int  vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane,
+                     int32_t nseq, int32_t S, int32_t S_pad, int32_t H, int32_t nsplit, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTAMIQ_HIP_H */

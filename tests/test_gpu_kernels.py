@@ -1,0 +1,130 @@
+"""Per-kernel parity on the GPU, through the C ABI, against fp64 torch references of the same op."""
+import math
+
+import pytest
+import torch
+
+from vtamiq_amd import _lib
+from tests.gpu_util import stream, to_planes, planes_value
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _randn(*s, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*s, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_split_bf16(nsplit):
+    x = _randn(1000, 768, seed=1)
+    p = to_planes(x, nsplit)
+    hi = x.bfloat16()
+    assert torch.equal(p[0], hi)
+    if nsplit == 3:
+        assert torch.equal(p[1], (x - hi.float()).bfloat16())
+        assert (planes_value(p) - x.double()).abs().max() < 2e-5 * x.abs().max()
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 768), (512, 768, 768), (768, 2304, 768), (256, 768, 3072), (512, 1024, 1024)])
+def test_gemm_bias(nsplit, M, N, K):
+    lib = _lib.load()
+    A, W, bias = _randn(M, K, seed=2), _randn(N, K, seed=3, scale=0.05), _randn(N, seed=4)
+    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
+    out = torch.zeros((Ap.shape[0], M, N), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 0, bias.data_ptr(), None, None,
+                              out.data_ptr(), M * N, N, stream()))
+    torch.cuda.synchronize()
+    if nsplit == 1:
+        ref = Ap[0].double() @ Wp[0].double().t() + bias.double()
+        tol = 1e-2          # output rounded to bf16
+    else:
+        ref = A.double() @ W.double().t() + bias.double()
+        tol = 1e-4
+    got = planes_value(out)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    # asymmetric data + non-square shapes: a transposed or permuted tile would be O(1) wrong
+    assert torch.allclose(got, ref, rtol=0, atol=tol * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_gemm_gelu(nsplit):
+    lib = _lib.load()
+    M, N, K = 256, 3072, 768
+    A, W, bias = _randn(M, K, seed=5), _randn(N, K, seed=6, scale=0.05), _randn(N, seed=7)
+    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
+    out = torch.zeros((Ap.shape[0], M, N), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 1, bias.data_ptr(), None, None,
+                              out.data_ptr(), M * N, N, stream()))
+    torch.cuda.synchronize()
+    pre = (planes_value(Ap) @ planes_value(Wp).t() + bias.double())
+    ref = torch.nn.functional.gelu(pre)
+    got = planes_value(out)
+    tol = 1e-2 if nsplit == 1 else 1e-4
+    assert (got - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("use_gamma", [False, True])
+def test_gemm_residual(nsplit, use_gamma):
+    lib = _lib.load()
+    M, N, K = 512, 768, 3072
+    A, W, bias = _randn(M, K, seed=8), _randn(N, K, seed=9, scale=0.02), _randn(N, seed=10)
+    gamma = _randn(N, seed=11) if use_gamma else None
+    x0 = _randn(M, N, seed=12)
+    x = x0.clone()
+    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 2, bias.data_ptr(),
+                              gamma.data_ptr() if use_gamma else None, x.data_ptr(), None, 0, 0, stream()))
+    torch.cuda.synchronize()
+    h = planes_value(Ap) @ planes_value(Wp).t() + bias.double()
+    ref = x0.double() + (gamma.double() * h if use_gamma else h)
+    assert (x.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("H", [768, 1024])
+def test_layernorm(nsplit, H):
+    lib = _lib.load()
+    rows = 515
+    x = _randn(rows, H, seed=13, scale=3.0) + 0.7
+    w, b = _randn(H, seed=14) + 1.0, _randn(H, seed=15)
+    out = torch.zeros((1 if nsplit == 1 else 2, rows, H), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.vtq_k_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), rows * H, rows, H, nsplit, stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (H,), w.double(), b.double(), 1e-6)
+    got = planes_value(out)
+    tol = 8e-3 if nsplit == 1 else 3e-5
+    assert (got - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
+def _attention_ref(qkv, nseq, S, S_pad, H):
+    nh = H // 64
+    x = qkv.view(nseq, S_pad, 3, nh, 64)[:, :S]
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(nseq, S, H)
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("nseq,S,H", [(4, 501, 768), (3, 51, 768), (2, 1025, 1024), (2, 64, 768), (2, 509, 768)])
+def test_attention(nsplit, nseq, S, H):
+    lib = _lib.load()
+    S_pad = (S + 63) // 64 * 64
+    rows = nseq * S_pad + 128
+    qkv = _randn(rows, 3 * H, seed=16, scale=1.5)
+    # a spike so that the running max moves late in the sequence (online-softmax rescale path)
+    qkv[S - 3, H:H + 64] *= 6.0
+    P = to_planes(qkv, nsplit)
+    npl = P.shape[0]
+    out = torch.zeros((npl, rows, H), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, out.data_ptr(), rows * H, nseq, S, S_pad, H, nsplit, stream()))
+    torch.cuda.synchronize()
+    ref = _attention_ref(planes_value(P)[: nseq * S_pad], nseq, S, S_pad, H)
+    got = planes_value(out)[: nseq * S_pad].view(nseq, S_pad, H)[:, :S]
+    tol = 1.5e-2 if nsplit == 1 else 2e-4
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err

@@ -1,0 +1,100 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every declared symbol; the product package never
+touches the oracle or the reference; the drop-in module exposes the reference's state_dict layout."""
+import ast
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vtamiq_amd import _lib, build
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "vtamiq_hip.h")).read()
+    declared = set(re.findall(r"\b(vtq_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vtq_engine"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.vtq_abi_version.restype = ctypes.c_int
+    assert lib.vtq_abi_version() == 1
+
+
+def test_config_struct_matches_header():
+    from vtamiq_amd import _lib
+    assert ctypes.sizeof(_lib.VtqConfig) == 20 * 4
+    assert ctypes.sizeof(_lib.VtqTensorDesc) == 24
+
+
+def test_product_never_imports_oracle_or_reference():
+    pkg = os.path.join(ROOT, "vtamiq_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            tree = ast.parse(src)
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                for n in names:
+                    assert not n.startswith("oracle"), (f, n)
+            assert "/root/reference" not in src, f
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, f)).read().replace('os.path.isdir("/root/reference")', "")
+
+
+def test_forward_fails_loudly_without_gpu():
+    from vtamiq_amd import VTAMIQ
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1), precision="bf16").eval()
+    p, pos = torch.zeros(1, 4, 3, 16, 16), torch.zeros(1, 4, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m((p, p), (pos, pos), (None, None))
+
+
+@pytest.mark.parametrize("kw,ntensors,nparams", [
+    (dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, path_drop_prob=0.1,
+                          num_scales=0), ca_reduction=16, rg_path_drop=0.1, predictor_dropout=0.1), 243, 57_322_386),
+    (dict(vit_config=dict(variant="ViT-B16")), 326, 101_014_674),
+])
+def test_state_dict_layout(kw, ntensors, nparams):
+    """Key names/shapes of SURVEY.md 8(b); counts probed on the reference (243 tensors / 57.3 M at config defaults)."""
+    from vtamiq_amd import VTAMIQ
+    m = VTAMIQ(**json.loads(json.dumps(kw)))
+    sd = m.state_dict()
+    layout = m.spec.state_layout()
+    assert sorted(sd) == sorted(k for k, _, _ in layout)
+    for k, shape, _ in layout:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert len(sd) == ntensors and sum(v.numel() for v in sd.values()) == nparams
+    assert len(m.transformer.encoder.layers) == m.spec.num_layers      # train.py:691 reads this
+
+
+def test_rejected_configs():
+    from vtamiq_amd import VTAMIQ
+    with pytest.raises(ValueError):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", use_cls_token=False))     # crashes in the reference too
+    with pytest.raises(NotImplementedError):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", num_adapters=2))
+    with pytest.raises(ValueError):
+        VTAMIQ(vit_config=dict(variant="ViT-H14"))
+
+
+def test_flop_model_matches_baseline_md():
+    from vtamiq_amd.spec import make_spec
+    s = make_spec(dict(variant="ViT-B16"))
+    assert abs(s.flops_per_pair(500) / 1.8992e11 - 1) < 1e-3
+    assert abs(s.flops_per_pair(50) / 1.7664e10 - 1) < 1e-3
+    d = make_spec(dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8), ca_reduction=16)
+    assert abs(d.flops_per_pair(500) / 9.7221e10 - 1) < 1e-3
+    l = make_spec(dict(variant="ViT-L16", num_scales=3))
+    assert abs(l.flops_per_pair(1024) / 1.4480e12 - 1) < 1e-3

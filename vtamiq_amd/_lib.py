@@ -1,0 +1,79 @@
+"""ctypes binding of libvtamiq_hip.so (include/vtamiq_hip.h).  No CPU fallback: if the library is missing or
+does not load, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtamiq_hip.so")
+
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+
+KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]
+
+
+class VtqConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "hidden_size", "mlp_dim", "num_heads", "num_layers", "patch_dim", "pos_grid", "num_extra_tokens", "num_scales",
+        "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs", "ca_hidden", "precision")] + [
+        ("reserved", C.c_int32 * 5)]
+
+
+class VtqTensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+# name -> (restype, argtypes): every symbol include/vtamiq_hip.h declares
+SIGNATURES = {
+    "vtq_abi_version": (C.c_int, []),
+    "vtq_last_error": (C.c_char_p, []),
+    "vtq_create": (C.c_int, [C.POINTER(VtqConfig), C.POINTER(C.c_void_p)]),
+    "vtq_destroy": (None, [C.c_void_p]),
+    "vtq_load_weights": (C.c_int, [C.c_void_p, C.POINTER(VtqTensorDesc), C.c_int32, C.c_void_p]),
+    "vtq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "vtq_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "vtq_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vtq_k_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "vtq_k_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                             C.c_void_p]),
+    "vtq_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
+    "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the engine library; RuntimeError (never a silent fallback) when it is absent or broken."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP engine is not built.  Run `python -m vtamiq_amd.build` "
+            "(there is no CPU fallback on the product path).")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vtq_abi_version() != 1:
+        raise RuntimeError("libvtamiq_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("vtamiq_hip: " + load().vtq_last_error().decode(errors="replace"))

@@ -1,0 +1,238 @@
+// Fused scaled-dot-product attention for gfx950, head_dim 64, no S x S tensor in HBM.
+//
+// Replaces MultiHeadSelfAttention.forward lines 158-166 of modules/VisionTransformer/transformer.py
+// (QK^T / sqrt(dh) -> softmax -> PV -> merge heads); the (B,h,S,S) probabilities the reference materialises and
+// returns (:161) are never formed.
+//
+// Structure (cdna_hip_programming.md Appendix B "fused attention", section 3 "accumulator tile as next operand"):
+//   * workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 query rows;
+//   * K/V tiles of 64 keys stream through LDS by 16-byte LDS-DMA, double buffered, one barrier per tile;
+//   * S^T = K Q^T with mfma_f32_32x32x16_bf16 (K fragment = A operand): the query index lands on the lane, so the
+//     online-softmax row statistics are lane-local (+ one lane^32 shuffle);
+//   * O^T += V^T P^T: the exponentiated accumulator registers 8s..8s+7 are the B-operand fragment of k-step s with no
+//     lane movement; V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
+//   * K tile chunks are XOR-swizzled ((row>>1)&7) for conflict-free ds_read_b128; V tile 64-byte halves are swapped on
+//     rows with bit 1 set so the four rows of a transposed read hit disjoint banks;
+//   * NSPLIT == 3: Q,K,V,P are hi/lo bf16 pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace vtq {
+namespace {
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, int64_t plane, bf16* __restrict__ out,
+                                                        int64_t o_plane, int S, int S_pad, int H) {
+    constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
+    constexpr int TB = 64 * 128;             // one 64-key x 64-dim bf16 tile
+    constexpr int STAGE = TB * NPL * 2;      // K planes then V planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int ld = 3 * H;
+    const int64_t row0 = (int64_t)blockIdx.z * S_pad;
+    const int q_row = blockIdx.x * 128 + wave * 32 + c;
+
+    // ---- Q fragments: B operand of S^T = K Q^T, element j <-> d = 16t + 8hh + j ------------------------------
+    bf16x8 qf[NPL][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            qf[pl][t] = *(const bf16x8*)(qkv + pl * plane + (row0 + q_row) * ld + head * 64 + 16 * t + 8 * hh);
+
+    // ---- DMA source offsets (elements) of this thread for the two rounds of a 64-row tile --------------------
+    uint32_t k_off[2], v_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int slot = r * 256 + tid;
+        const int row = slot >> 3, s = slot & 7;
+        k_off[r] = (uint32_t)(row * ld + H + head * 64 + ((s ^ ((row >> 1) & 7)) << 3));
+        v_off[r] = (uint32_t)(row * ld + 2 * H + head * 64 + ((s ^ (((row >> 1) & 1) << 2)) << 3));
+    }
+    auto stage = [&](int t, int buf) {
+        char* sb = smem + buf * STAGE + wave * 1024;
+        const bf16* base = qkv + (row0 + (int64_t)t * 64) * ld;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                glds16(base + pl * plane + k_off[r], sb + pl * TB + r * 4096);
+                glds16(base + pl * plane + v_off[r], sb + (NPL + pl) * TB + r * 4096);
+            }
+    };
+
+    // K fragment read offset: row = kb*32 + c, chunk = 2t + hh, swizzle (row>>1)&7 == (c>>1)&7
+    const int k_rd = c * 128;
+    const int k_sw = (c >> 1) & 7;
+    // V transposed-read offsets: 16-lane group g, lane i = 4*qq + pp supplies row qq, columns 4pp..4pp+3
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int v_row = 4 * (g >> 1) + qq;                                        // + kb*32 + 16*s2 (+8)
+    const int v_colb = ((16 * (g & 1) + 4 * pp) * 2) ^ (((qq >> 1) & 1) << 6);  // d-block toggles bit 6 too (XOR)
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float sc = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
+
+    const int nt = S_pad / 64;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        const char* sk = smem + cur * STAGE;
+        const char* sv = sk + NPL * TB;
+
+        // ---- S^T[key][q] for the 64 keys of this tile ---------------------------------------------------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int off = kb * 32 * 128 + k_rd + (((2 * tt + hh) ^ k_sw) << 4);
+                const bf16x8 kf = *(const bf16x8*)(sk + off);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], sacc[kb], 0, 0, 0);
+                if constexpr (NSPLIT == 3) {
+                    const bf16x8 kl = *(const bf16x8*)(sk + TB + off);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][tt], sacc[kb], 0, 0, 0);
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][tt], sacc[kb], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- online softmax (base-2 domain) -------------------------------------------------------------------
+        const bool tail = (t == nt - 1) && (S < S_pad);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = sacc[kb][r] * sc;
+                if (tail) {
+                    const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= S) s = -INFINITY;
+                }
+                sacc[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(sacc[kb][r] - m_new);
+                sacc[kb][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+
+        // ---- O^T[d][q] += V^T[d][key] P^T[key][q] -------------------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl_;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = sacc[kb][8 * s2 + j];
+                    if constexpr (NSPLIT == 1) ph[j] = (bf16)pv;
+                    else { bf16 a, b; split2(pv, a, b); ph[j] = a; pl_[j] = b; }
+                }
+                const int vrow = kb * 32 + 16 * s2 + v_row;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    // byte column of (d-block, 16-column half, 4-column piece); bit 6 carries the row swizzle
+                    const char* a0 = sv + vrow * 128 + (v_colb ^ (d << 6));
+                    const bf16x4 v0 = lds_tr16(a0);
+                    const bf16x4 v1 = lds_tr16(a0 + 8 * 128);
+                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, o_acc[d], 0, 0, 0);
+                    if constexpr (NSPLIT == 3) {
+                        const bf16x4 w0 = lds_tr16(a0 + TB);
+                        const bf16x4 w1 = lds_tr16(a0 + TB + 8 * 128);
+                        const bf16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pl_, o_acc[d], 0, 0, 0);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o_acc[d], 0, 0, 0);
+                    }
+                }
+            }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < S_pad) {
+        bf16* o = out + (row0 + q_row) * H + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dcol = 32 * d + 8 * g4 + 4 * hh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
+                if constexpr (NSPLIT == 1) {
+                    bf16x4 hv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)(o + dcol) = hv;
+                } else {
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16 a, b; split2(v[e], a, b); hv[e] = a; lv[e] = b; }
+                    *(bf16x4*)(o + dcol) = hv;
+                    *(bf16x4*)(o + o_plane + dcol) = lv;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
+                            int nsplit, hipStream_t s) {
+    if (H % 64 || S_pad % 64 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
+    const dim3 grid((S_pad + 127) / 128, H / 64, nseq), blk(256);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(attention_kernel<1>, grid, blk, 2 * 64 * 128 * 2, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S,
+                           S_pad, H);
+    } else {
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * 64 * 128 * 4);
+            if (e != hipSuccess) return e;
+            configured = true;
+        }
+        hipLaunchKernelGGL(attention_kernel<3>, grid, blk, 2 * 64 * 128 * 4, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S,
+                           S_pad, H);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace vtq

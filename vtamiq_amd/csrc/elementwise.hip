@@ -1,0 +1,249 @@
+// HBM-bound kernels of the ViT path: fp32 -> bf16(hi,lo) packing, LayerNorm, embedding index/token rows.
+// One wave per row where a row reduction is needed (wave64 shuffles, no LDS); 16-byte vector accesses everywhere.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace vtq {
+namespace {
+
+template <int NSPLIT>
+__device__ __forceinline__ void store4(bf16* dst, int64_t plane, float a, float b, float c, float d) {
+    if constexpr (NSPLIT == 1) {
+        bf16x4 h = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+        *(bf16x4*)dst = h;
+    } else {
+        bf16x4 h, l;
+        bf16 x, y;
+        split2(a, x, y); h[0] = x; l[0] = y;
+        split2(b, x, y); h[1] = x; l[1] = y;
+        split2(c, x, y); h[2] = x; l[2] = y;
+        split2(d, x, y); h[3] = x; l[3] = y;
+        *(bf16x4*)dst = h;
+        *(bf16x4*)(dst + plane) = l;
+    }
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t plane,
+                                                    int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)src)[i];
+        store4<NSPLIT>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+    }
+}
+
+// rows [0,BN) from ref, [BN,2BN) from dist, [2BN,rows_pad) zero.  K = 768 floats per row.
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void pack_patches_kernel(const float* __restrict__ ref, const float* __restrict__ dist,
+                                                           bf16* __restrict__ dst, int64_t plane, int BN, int K4,
+                                                           int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / K4;
+        const int c4 = (int)(i - row * K4);
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < BN) v = ((const float4*)ref)[row * K4 + c4];
+        else if (row < 2 * (int64_t)BN) v = ((const float4*)dist)[(row - BN) * K4 + c4];
+        store4<NSPLIT>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+    }
+}
+
+// UvPosEmbedding.forward index (transformer.py:417-421): floor(pos*G) -> i0*G + i1 + 1, evaluated in fp32 like torch;
+// ScaleEmbedding.forward index (transformer.py:396-398): clamp(scale, 0, num_scales-1) + 1.
+__global__ void embed_index_kernel(const float* __restrict__ pos_ref, const float* __restrict__ pos_dist,
+                                   const float* __restrict__ sc_ref, const float* __restrict__ sc_dist, int* __restrict__ pidx,
+                                   int* __restrict__ sidx, int* __restrict__ row_map, int B, int N, int rows_pad, int S_pad,
+                                   int T, int grid, int num_scales) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows_pad) return;
+    const int BN = B * N;
+    if (r >= 2 * BN) { pidx[r] = 0; sidx[r] = 0; row_map[r] = -1; return; }
+    const int side = r >= BN;
+    const int rr = r - side * BN;
+    const float* pp = (side ? pos_dist : pos_ref) + (int64_t)rr * 2;
+    const float g = (float)grid;
+    const float f0 = floorf(pp[0] * g), f1 = floorf(pp[1] * g);
+    pidx[r] = (int)(f0 * g + f1 + 1.0f);
+    int si = 0;
+    if (sc_ref) {
+        float sv = (side ? sc_dist : sc_ref)[rr];
+        sv = fminf(fmaxf(sv, 0.0f), (float)(num_scales - 1)) + 1.0f;
+        si = (int)sv;
+    }
+    sidx[r] = si;
+    const int b = rr / N, n = rr - b * N;
+    row_map[r] = (side * B + b) * S_pad + T + n;
+}
+
+// Embeddings.forward_tokens (transformer.py:507-524): row 0 = cls + pos_table[0]; rows 1..T-1 = register tokens.
+__global__ void tokens_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos_table,
+                              const float* __restrict__ extra, int S_pad, int T, int H) {
+    const int seq = blockIdx.x, t = blockIdx.y;
+    float* dst = x + ((int64_t)seq * S_pad + t) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) dst[c] = (t == 0) ? cls[c] + pos_table[c] : extra[(t - 1) * H + c];
+}
+
+__global__ void zero_pad_rows_kernel(float* __restrict__ x, int nseq, int S, int S_pad, int H4, int rows_total) {
+    const int per_seq = S_pad - S;
+    const int npad = nseq * per_seq + (rows_total - nseq * S_pad);
+    for (int i = blockIdx.x; i < npad; i += gridDim.x) {
+        int64_t row;
+        if (i < nseq * per_seq) { const int sq = i / per_seq; row = (int64_t)sq * S_pad + S + (i - sq * per_seq); }
+        else row = (int64_t)nseq * S_pad + (i - nseq * per_seq);
+        float4* d = (float4*)x + row * H4;
+        for (int c = threadIdx.x; c < H4; c += blockDim.x) d[c] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ void copy_tokens_kernel(const float* __restrict__ x, float* __restrict__ dst, int S_pad, int T, int H) {
+    const int seq = blockIdx.x, t = blockIdx.y;
+    const float* src = x + ((int64_t)seq * S_pad + t) * H;
+    float* d = dst + ((int64_t)seq * T + t) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) d[c] = src[c];
+}
+
+// torch.nn.LayerNorm(H, eps=1e-6) (transformer.py:253-254): two-pass fp32 statistics held in registers.
+// One wave per row, V4 float4 per lane (H = 256*V4).
+template <int V4>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ w, const float* __restrict__ b,
+                                       int lane, float4 (&y)[V4]) {
+    constexpr int H = 256 * V4;
+    float4 v[V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i] = ((const float4*)xr)[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const float4 w4 = ((const float4*)w)[i * 64 + lane];
+        const float4 b4 = ((const float4*)b)[i * 64 + lane];
+        y[i].x = v[i].x * rstd * w4.x + b4.x;
+        y[i].y = v[i].y * rstd * w4.y + b4.y;
+        y[i].z = v[i].z * rstd * w4.z + b4.z;
+        y[i].w = v[i].w * rstd * w4.w + b4.w;
+    }
+}
+
+template <int V4, int NSPLIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16* __restrict__ out, int64_t o_plane,
+                                                        int rows) {
+    constexpr int H = 256 * V4;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 y[V4];
+    ln_row<V4>(x + (int64_t)row * H, w, b, lane, y);
+    bf16* o = out + (int64_t)row * H;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) store4<NSPLIT>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w);
+}
+
+// encoder_norm on the two CLS rows of pair b only (transformer.py:376 applies it to all rows; only token 0 is
+// consumed, vtamiq.py:107-108), then diff and diff_scale (vtamiq.py:111).
+template <int V4>
+__global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ gamma,
+                                                        float* __restrict__ d, int B, int S_pad) {
+    constexpr int H = 256 * V4;
+    const int lane = threadIdx.x;
+    const int pb = blockIdx.x;
+    float4 yr[V4], yd[V4];
+    ln_row<V4>(x + (int64_t)pb * S_pad * H, w, b, lane, yr);
+    ln_row<V4>(x + (int64_t)(B + pb) * S_pad * H, w, b, lane, yd);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        float4 r = {yr[i].x - yd[i].x, yr[i].y - yd[i].y, yr[i].z - yd[i].z, yr[i].w - yd[i].w};
+        if (gamma) {
+            const float4 g4 = ((const float4*)gamma)[i * 64 + lane];
+            r.x *= g4.x; r.y *= g4.y; r.z *= g4.z; r.w *= g4.w;
+        }
+        ((float4*)(d + (int64_t)pb * H))[i * 64 + lane] = r;
+    }
+}
+
+inline int grid_for(int64_t work, int block) {
+    int64_t g = (work + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s) {
+    if (numel % 4) return hipErrorInvalidValue;
+    const int64_t n4 = numel / 4;
+    if (nsplit == 1) hipLaunchKernelGGL(split_kernel<1>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, plane, n4);
+    else hipLaunchKernelGGL(split_kernel<3>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, plane, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_patches(const float* ref, const float* dist, void* dst, int64_t plane, int BN, int K, int rows_pad,
+                               int nsplit, hipStream_t s) {
+    const int K4 = K / 4;
+    const int64_t total4 = (int64_t)rows_pad * K4;
+    if (nsplit == 1)
+        hipLaunchKernelGGL(pack_patches_kernel<1>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ref, dist, (bf16*)dst, plane,
+                           BN, K4, total4);
+    else
+        hipLaunchKernelGGL(pack_patches_kernel<3>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ref, dist, (bf16*)dst, plane,
+                           BN, K4, total4);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_index(const float* pos_ref, const float* pos_dist, const float* sc_ref, const float* sc_dist, int* pidx,
+                              int* sidx, int* row_map, int B, int N, int rows_pad, int S_pad, int T, int grid, int num_scales,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pos_ref, pos_dist, sc_ref, sc_dist,
+                       pidx, sidx, row_map, B, N, rows_pad, S_pad, T, grid, num_scales);
+    return hipGetLastError();
+}
+
+hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, int S_pad, int T,
+                         int H, hipStream_t s) {
+    hipLaunchKernelGGL(tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, cls, pos_table, extra, S_pad, T, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_pad_rows(float* x, int nseq, int S, int S_pad, int H, int rows_total, hipStream_t s) {
+    const int npad = nseq * (S_pad - S) + (rows_total - nseq * S_pad);
+    if (npad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(npad < 4096 ? npad : 4096), dim3(256), 0, s, x, nseq, S, S_pad, H / 4, rows_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, int S_pad, int T, int H, hipStream_t s) {
+    hipLaunchKernelGGL(copy_tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, dst, S_pad, T, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
+                            int nsplit, hipStream_t s) {
+    const dim3 g((rows + 3) / 4), blk(256);
+#define VTQ_LN(V4, NS) hipLaunchKernelGGL((layernorm_kernel<V4, NS>), g, blk, 0, s, x, w, b, (bf16*)out, o_plane, rows)
+    if (H == 768 && nsplit == 1) VTQ_LN(3, 1);
+    else if (H == 768 && nsplit == 3) VTQ_LN(3, 3);
+    else if (H == 1024 && nsplit == 1) VTQ_LN(4, 1);
+    else if (H == 1024 && nsplit == 3) VTQ_LN(4, 3);
+    else return hipErrorInvalidValue;
+#undef VTQ_LN
+    return hipGetLastError();
+}
+
+hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B,
+                             int S_pad, int H, hipStream_t s) {
+    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
+    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace vtq

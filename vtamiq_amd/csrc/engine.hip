@@ -1,0 +1,494 @@
+// libvtamiq_hip.so: C ABI (include/vtamiq_hip.h) around the gfx950 kernels.
+//
+// One engine = one VTAMIQ model instance on one GPU: packed weights (bf16 hi[/lo] planes for the ViT GEMMs, fp32 for
+// everything else), a workspace sized for the largest (B, N) seen, and the launch sequence of VTAMIQ.forward
+// (modules/vtamiq/vtamiq.py:94-119) with both images of a pair batched as 2B sequences through ONE encoder pass
+// (the reference runs two serial passes with the same weights, vtamiq.py:100-101).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vtamiq_hip.h"
+#include "kernels.h"
+
+using namespace vtq;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct Slot {
+    void* dst = nullptr;      // destination (fp32 copy) or bf16 hi plane (split)
+    int64_t numel = 0;
+    bool split = false;       // true: pack to bf16 planes
+    int64_t plane = 0;        // elements between hi and lo plane
+    bool loaded = false;
+};
+
+struct Layer {
+    void *wqkv, *wo, *w1, *w2;                 // bf16 planes
+    int64_t pqkv, po, p1, p2;                  // plane strides
+    float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b, *g1, *g2;
+};
+struct Rcab { float *slope, *w, *b, *wd, *bd, *wu, *bu; };
+struct Rg { std::vector<Rcab> rcabs; float *w, *b; };
+
+}  // namespace
+
+struct vtq_engine {
+    vtq_config cfg{};
+    int nsplit = 1, npl = 1;
+    int H = 0, Mdim = 0, T = 0;
+    std::vector<void*> allocs;
+    std::unordered_map<std::string, Slot> slots;
+    // ViT
+    void* wpatch = nullptr; int64_t ppatch = 0;
+    float *bpatch = nullptr, *cls = nullptr, *extra = nullptr, *pos_table = nullptr, *scale_table = nullptr, *encw = nullptr,
+          *encb = nullptr;
+    std::vector<Layer> layers;
+    // head
+    float* diff_gamma = nullptr;
+    std::vector<Rg> rgs;
+    float *qdw = nullptr, *qdb = nullptr, *p1w = nullptr, *p1b = nullptr, *p2a = nullptr, *p4w = nullptr, *p4b = nullptr;
+    // workspace
+    int capB = 0, capN = 0;
+    int64_t rows_alloc = 0;
+    float* x = nullptr;
+    void *lnbuf = nullptr, *big = nullptr;
+    int64_t ln_plane = 0, big_plane = 0;
+    int *pidx = nullptr, *sidx = nullptr, *row_map = nullptr;
+    float* hb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* hhid = nullptr;
+    std::vector<void*> ws_allocs;
+    float* trace = nullptr;
+    // profiling
+    uint32_t prof_mask = 0;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+};
+
+namespace {
+
+int dev_alloc(vtq_engine* e, void** p, size_t bytes, bool ws = false) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    (ws ? e->ws_allocs : e->allocs).push_back(*p);
+    return 0;
+}
+
+int add_f32(vtq_engine* e, const std::string& name, float** p, int64_t numel) {
+    if (dev_alloc(e, (void**)p, numel * sizeof(float))) return 1;
+    Slot s; s.dst = *p; s.numel = numel;
+    e->slots[name] = s;
+    return 0;
+}
+
+// bf16 planes for a [rows_total, K] weight; sub-slot `name` covers rows [row0, row0 + rows)
+int add_split(vtq_engine* e, const std::string& name, void* base, int64_t plane, int64_t row0, int64_t rows, int64_t K) {
+    Slot s; s.dst = (char*)base + row0 * K * 2; s.numel = rows * K; s.split = true; s.plane = plane;
+    e->slots[name] = s;
+    return 0;
+}
+
+int alloc_planes(vtq_engine* e, void** p, int64_t* plane, int64_t numel) {
+    *plane = numel;
+    return dev_alloc(e, p, (size_t)numel * 2 * e->npl);
+}
+
+int build(vtq_engine* e) {
+    const vtq_config& c = e->cfg;
+    const int64_t H = c.hidden_size, M = c.mlp_dim, PD = c.patch_dim;
+    const std::string emb = "transformer.embeddings.";
+    if (add_f32(e, emb + "cls_token", &e->cls, H)) return 1;
+    if (c.num_extra_tokens > 0 && add_f32(e, emb + "extra_tokens", &e->extra, (int64_t)c.num_extra_tokens * H)) return 1;
+    if (alloc_planes(e, &e->wpatch, &e->ppatch, H * PD)) return 1;
+    add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD);
+    if (add_f32(e, emb + "patch_embeddings.bias", &e->bpatch, H)) return 1;
+    if (add_f32(e, emb + "positional_embeddings.positional_embeddings", &e->pos_table, ((int64_t)c.pos_grid * c.pos_grid + 1) * H))
+        return 1;
+    if (c.num_scales > 1 && add_f32(e, emb + "scale_embeddings.scale_embeddings", &e->scale_table, ((int64_t)c.num_scales + 1) * H))
+        return 1;
+    const std::string enc = "transformer.encoder.";
+    if (add_f32(e, enc + "encoder_norm.weight", &e->encw, H) || add_f32(e, enc + "encoder_norm.bias", &e->encb, H)) return 1;
+    e->layers.resize(c.num_layers);
+    for (int i = 0; i < c.num_layers; ++i) {
+        Layer& L = e->layers[i];
+        memset(&L, 0, sizeof L);
+        const std::string p = enc + "layers." + std::to_string(i) + ".";
+        if (alloc_planes(e, &L.wqkv, &L.pqkv, 3 * H * H) || alloc_planes(e, &L.wo, &L.po, H * H) ||
+            alloc_planes(e, &L.w1, &L.p1, M * H) || alloc_planes(e, &L.w2, &L.p2, H * M))
+            return 1;
+        if (dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float))) return 1;
+        const char* qkvn[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            add_split(e, p + "attn." + qkvn[j] + ".weight", L.wqkv, L.pqkv, j * H, H, H);
+            Slot s; s.dst = L.bqkv + j * H; s.numel = H;
+            e->slots[p + "attn." + qkvn[j] + ".bias"] = s;
+        }
+        add_split(e, p + "attn.out.weight", L.wo, L.po, 0, H, H);
+        add_split(e, p + "ffn.fc1.weight", L.w1, L.p1, 0, M, H);
+        add_split(e, p + "ffn.fc2.weight", L.w2, L.p2, 0, H, M);
+        if (add_f32(e, p + "attn.out.bias", &L.bo, H) || add_f32(e, p + "ffn.fc1.bias", &L.b1, M) ||
+            add_f32(e, p + "ffn.fc2.bias", &L.b2, H) || add_f32(e, p + "attention_norm.weight", &L.ln1w, H) ||
+            add_f32(e, p + "attention_norm.bias", &L.ln1b, H) || add_f32(e, p + "ffn_norm.weight", &L.ln2w, H) ||
+            add_f32(e, p + "ffn_norm.bias", &L.ln2b, H))
+            return 1;
+        if (c.use_layer_scale && (add_f32(e, p + "ls1.gamma", &L.g1, H) || add_f32(e, p + "ls2.gamma", &L.g2, H))) return 1;
+    }
+    if (c.diff_scale && add_f32(e, "diff_scale.gamma", &e->diff_gamma, H)) return 1;
+    if (c.calibrate) {
+        const int64_t hid = c.ca_hidden;
+        e->rgs.resize(c.num_rgs);
+        for (int g = 0; g < c.num_rgs; ++g) {
+            Rg& R = e->rgs[g];
+            R.rcabs.resize(c.num_rcabs);
+            for (int k = 0; k < c.num_rcabs; ++k) {
+                Rcab& r = R.rcabs[k];
+                const std::string p = "quality_decoder." + std::to_string(g) + ".body." + std::to_string(k) + ".body.";
+                if (add_f32(e, p + "1.weight", &r.slope, 1) || add_f32(e, p + "2.weight", &r.w, H * H) ||
+                    add_f32(e, p + "2.bias", &r.b, H) || add_f32(e, p + "4.conv_du.1.weight", &r.wd, hid * H) ||
+                    add_f32(e, p + "4.conv_du.1.bias", &r.bd, hid) || add_f32(e, p + "4.conv_du.4.weight", &r.wu, H * hid) ||
+                    add_f32(e, p + "4.conv_du.4.bias", &r.bu, H))
+                    return 1;
+            }
+            const std::string p = "quality_decoder." + std::to_string(g) + ".body." + std::to_string(c.num_rcabs) + ".";
+            if (add_f32(e, p + "weight", &R.w, H * H) || add_f32(e, p + "bias", &R.b, H)) return 1;
+        }
+        const std::string p = "quality_decoder." + std::to_string(c.num_rgs) + ".";
+        if (add_f32(e, p + "weight", &e->qdw, H * H) || add_f32(e, p + "bias", &e->qdb, H)) return 1;
+    }
+    if (add_f32(e, "q_predictor.1.weight", &e->p1w, (H / 4) * H) || add_f32(e, "q_predictor.1.bias", &e->p1b, H / 4) ||
+        add_f32(e, "q_predictor.2.weight", &e->p2a, 1) || add_f32(e, "q_predictor.4.weight", &e->p4w, H / 4) ||
+        add_f32(e, "q_predictor.4.bias", &e->p4b, 1))
+        return 1;
+    return 0;
+}
+
+struct Geometry {
+    int S, S_pad, nseq;
+    int64_t M_pad, P_pad, rows_alloc;
+};
+
+Geometry geometry(const vtq_engine* e, int B, int N) {
+    Geometry g;
+    g.S = N + e->T;
+    g.S_pad = (int)round_up(g.S, 64);
+    g.nseq = 2 * B;
+    g.M_pad = round_up((int64_t)g.nseq * g.S_pad, 256);
+    g.P_pad = round_up((int64_t)2 * B * N, 256);
+    g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention query over-read slack
+    return g;
+}
+
+size_t workspace_bytes(const vtq_engine* e, int B, int N) {
+    const Geometry g = geometry(e, B, N);
+    const int64_t H = e->H, Wmax = (3 * H > e->Mdim ? 3 * H : e->Mdim);
+    size_t b = 0;
+    b += (size_t)g.rows_alloc * H * 4;                    // residual stream fp32
+    b += (size_t)g.rows_alloc * H * 2 * e->npl;           // LN / attention output planes
+    b += (size_t)g.rows_alloc * Wmax * 2 * e->npl;        // qkv | mlp hidden | packed patches planes
+    b += (size_t)g.P_pad * 4 * 3;                         // pos/scale indices, row map
+    b += (size_t)B * H * 4 * 5 + (size_t)B * (H / 4) * 4; // head ping-pong buffers
+    return b;
+}
+
+int reserve(vtq_engine* e, int B, int N) {
+    if (B <= e->capB && N <= e->capN && e->x) return 0;
+    const int nB = B > e->capB ? B : e->capB, nN = N > e->capN ? N : e->capN;
+    HIP_TRY(hipDeviceSynchronize());
+    for (void* p : e->ws_allocs) (void)hipFree(p);
+    e->ws_allocs.clear();
+    e->x = nullptr;
+    const Geometry g = geometry(e, nB, nN);
+    const int64_t H = e->H, Wmax = (3 * H > e->Mdim ? 3 * H : e->Mdim);
+    e->rows_alloc = g.rows_alloc;
+    e->ln_plane = g.rows_alloc * H;
+    e->big_plane = g.rows_alloc * Wmax;
+    if (dev_alloc(e, (void**)&e->x, (size_t)g.rows_alloc * H * 4, true) ||
+        dev_alloc(e, &e->lnbuf, (size_t)e->ln_plane * 2 * e->npl, true) ||
+        dev_alloc(e, &e->big, (size_t)e->big_plane * 2 * e->npl, true) ||
+        dev_alloc(e, (void**)&e->pidx, (size_t)g.P_pad * 4, true) || dev_alloc(e, (void**)&e->sidx, (size_t)g.P_pad * 4, true) ||
+        dev_alloc(e, (void**)&e->row_map, (size_t)g.P_pad * 4, true) ||
+        dev_alloc(e, (void**)&e->hhid, (size_t)nB * (H / 4) * 4, true))
+        return 1;
+    for (int i = 0; i < 5; ++i)
+        if (dev_alloc(e, (void**)&e->hb[i], (size_t)nB * H * 4, true)) return 1;
+    // finite contents everywhere: padded rows are computed on (never consumed) and must not breed NaNs
+    HIP_TRY(hipMemset(e->x, 0, (size_t)g.rows_alloc * H * 4));
+    HIP_TRY(hipMemset(e->lnbuf, 0, (size_t)e->ln_plane * 2 * e->npl));
+    HIP_TRY(hipMemset(e->big, 0, (size_t)e->big_plane * 2 * e->npl));
+    HIP_TRY(hipDeviceSynchronize());
+    e->capB = nB;
+    e->capN = nN;
+    return 0;
+}
+
+struct Prof {
+    vtq_engine* e; hipStream_t s; int cls; bool on; hipEvent_t a, b;
+    Prof(vtq_engine* e_, hipStream_t s_, int cls_) : e(e_), s(s_), cls(cls_), on((e_->prof_mask >> cls_) & 1u) {
+        if (!on) return;
+        if (!e->ev_free.empty()) { a = e->ev_free.back().first; b = e->ev_free.back().second; e->ev_free.pop_back(); }
+        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(a, s);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        e->ev_used.push_back({a, b, cls});
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int vtq_abi_version(void) { return VTQ_ABI_VERSION; }
+const char* vtq_last_error(void) { return g_err.c_str(); }
+
+int vtq_create(const vtq_config* cfg, vtq_handle* out) {
+    if (!cfg || !out) return fail("vtq_create: null argument");
+    const vtq_config& c = *cfg;
+    if (c.hidden_size != 768 && c.hidden_size != 1024) return fail("hidden_size %d unsupported (768 | 1024)", c.hidden_size);
+    if (c.num_heads <= 0 || c.hidden_size / c.num_heads != 64 || c.hidden_size % c.num_heads)
+        return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
+    if (c.mlp_dim % 256 || c.mlp_dim <= 0) return fail("mlp_dim %d must be a positive multiple of 256", c.mlp_dim);
+    if (c.patch_dim != 768) return fail("patch_dim %d unsupported (3*16*16 only)", c.patch_dim);
+    if (c.num_layers < 1 || c.pos_grid < 1 || c.num_extra_tokens < 0) return fail("bad topology");
+    if (c.calibrate && (c.num_rgs < 1 || c.num_rcabs < 1 || c.ca_hidden < 4 || c.ca_hidden % 4 || c.ca_hidden > 256))
+        return fail("bad DiffNet topology (rgs %d, rcabs %d, ca_hidden %d)", c.num_rgs, c.num_rcabs, c.ca_hidden);
+    if (c.precision != VTQ_PREC_BF16 && c.precision != VTQ_PREC_BF16X3) return fail("unknown precision %d", c.precision);
+    vtq_engine* e = new vtq_engine();
+    e->cfg = c;
+    e->nsplit = c.precision == VTQ_PREC_BF16 ? 1 : 3;
+    e->npl = c.precision == VTQ_PREC_BF16 ? 1 : 2;
+    e->H = c.hidden_size;
+    e->Mdim = c.mlp_dim;
+    e->T = 1 + c.num_extra_tokens;
+    if (build(e)) { vtq_destroy(e); return 1; }
+    *out = e;
+    return 0;
+}
+
+void vtq_destroy(vtq_handle e) {
+    if (!e) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (void* p : e->ws_allocs) (void)hipFree(p);
+    for (auto& ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete e;
+}
+
+int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void* stream) {
+    if (!e || !descs) return fail("vtq_load_weights: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        const vtq_tensor_desc& d = descs[i];
+        if (!d.name || !d.data) return fail("vtq_load_weights: descriptor %d has a null field", i);
+        auto it = e->slots.find(d.name);
+        if (it == e->slots.end()) return fail("vtq_load_weights: unexpected tensor '%s'", d.name);
+        Slot& sl = it->second;
+        if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
+        if (sl.split) HIP_TRY(launch_split_bf16(d.data, sl.dst, sl.plane, sl.numel, e->nsplit, s));
+        else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
+        sl.loaded = true;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+size_t vtq_workspace_bytes(vtq_handle e, int32_t B, int32_t N) { return e ? workspace_bytes(e, B, N) : 0; }
+
+int vtq_reserve(vtq_handle e, int32_t B, int32_t N) {
+    if (!e || B < 1 || N < 1) return fail("vtq_reserve: bad argument");
+    return reserve(e, B, N);
+}
+
+int vtq_set_token_trace(vtq_handle e, float* buf) {
+    if (!e) return fail("null handle");
+    e->trace = buf;
+    return 0;
+}
+
+int vtq_profile_enable(vtq_handle e, uint32_t mask) {
+    if (!e) return fail("null handle");
+    e->prof_mask = mask;
+    return 0;
+}
+
+int vtq_profile_collect(vtq_handle e, double* ms_sum, int64_t* launches) {
+    if (!e || !ms_sum || !launches) return fail("vtq_profile_collect: null argument");
+    for (int k = 0; k < VTQ_K_COUNT; ++k) { ms_sum[k] = 0; launches[k] = 0; }
+    for (auto& ev : e->ev_used) {
+        HIP_TRY(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        ms_sum[ev.cls] += ms;
+        launches[ev.cls] += 1;
+        e->ev_free.push_back({ev.a, ev.b});
+    }
+    e->ev_used.clear();
+    return 0;
+}
+
+int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
+                const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
+    if (!e) return fail("vtq_forward: null handle");
+    if (!patches_ref || !patches_dist || !pos_ref || !pos_dist || !q_out) return fail("vtq_forward: null tensor");
+    if (B < 1 || N < 1) return fail("vtq_forward: B=%d N=%d", B, N);
+    const vtq_config& c = e->cfg;
+    const bool use_scales = c.num_scales > 1;
+    if (use_scales && (!scales_ref || !scales_dist))
+        return fail("Model uses scale embedding but scales is passed as None.");   // transformer.py:547-548
+    for (auto& kv : e->slots)
+        if (!kv.second.loaded) return fail("vtq_forward: weight '%s' was never loaded", kv.first.c_str());
+    if (reserve(e, B, N)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    const Geometry g = geometry(e, B, N);
+    const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit;
+    const int L = c.num_layers;
+
+    // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
+    {
+        Prof p(e, s, VTQ_K_CONVERT);
+        HIP_TRY(launch_pack_patches(patches_ref, patches_dist, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, ns, s));
+        HIP_TRY(launch_embed_index(pos_ref, pos_dist, use_scales ? scales_ref : nullptr, use_scales ? scales_dist : nullptr, e->pidx,
+                                   e->sidx, e->row_map, B, N, (int)g.P_pad, g.S_pad, T, c.pos_grid, c.num_scales, s));
+        HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.S_pad, H, (int)e->rows_alloc, s));
+        HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.S_pad, T, H, s));
+    }
+    {
+        Prof p(e, s, VTQ_K_PATCH);
+        GemmArgs a{};
+        a.A = e->big; a.a_plane = e->big_plane; a.lda = c.patch_dim;
+        a.W = e->wpatch; a.w_plane = e->ppatch;
+        a.M = (int)g.P_pad; a.N = H; a.K = c.patch_dim;
+        a.bias = e->bpatch; a.x = e->x;
+        a.row_map = e->row_map; a.idx1 = e->pidx; a.table1 = e->pos_table;
+        a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
+        HIP_TRY(launch_gemm(a, ns, EPI_EMBED, s));
+    }
+    const int64_t trace_stride = (int64_t)g.nseq * T * H;
+    if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.S_pad, T, H, s));
+
+    // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
+    const int M = (int)g.M_pad;
+    for (int i = 0; i < L; ++i) {
+        const Layer& Ly = e->layers[i];
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln1w, Ly.ln1b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
+        {
+            Prof p(e, s, VTQ_K_QKV);
+            GemmArgs a{};
+            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
+            a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = e->big; a.o_plane = e->big_plane; a.ldo = 3 * H;
+            HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+        }
+        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(e->big, e->big_plane, e->lnbuf, e->ln_plane, g.nseq, g.S, g.S_pad, H, ns, s)); }
+        {
+            Prof p(e, s, VTQ_K_OUTPROJ);
+            GemmArgs a{};
+            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
+            a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = e->x;
+            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+        }
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln2w, Ly.ln2b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
+        {
+            Prof p(e, s, VTQ_K_FC1);
+            GemmArgs a{};
+            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
+            a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = e->big; a.o_plane = e->big_plane; a.ldo = Md;
+            HIP_TRY(launch_gemm(a, ns, EPI_BIAS_GELU, s));
+        }
+        {
+            Prof p(e, s, VTQ_K_FC2);
+            GemmArgs a{};
+            a.A = e->big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
+            a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = e->x;
+            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+        }
+        if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace + (i + 1) * trace_stride, g.nseq, g.S_pad, T, H, s));
+    }
+
+    // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------
+    {
+        Prof p(e, s, VTQ_K_HEAD);
+        float* d = e->hb[0];
+        HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, g.S_pad, H, s));
+        if (c.calibrate) {
+            float* xr = e->hb[0];       // residual-group input
+            float* xr_next = e->hb[1];
+            float *y0 = e->hb[2], *y1 = e->hb[3], *cb = e->hb[4];
+            for (auto& R : e->rgs) {
+                const float* y = xr;
+                float* yo = y0;
+                for (auto& r : R.rcabs) {
+                    HIP_TRY(launch_small_linear(y, r.w, r.b, r.slope, nullptr, nullptr, cb, B, H, H, s));
+                    HIP_TRY(launch_ca_residual(cb, y, r.wd, r.bd, r.wu, r.bu, yo, B, H, c.ca_hidden, s));
+                    y = yo;
+                    yo = (yo == y0) ? y1 : y0;
+                }
+                HIP_TRY(launch_small_linear(y, R.w, R.b, nullptr, nullptr, xr, xr_next, B, H, H, s));
+                float* t = xr; xr = xr_next; xr_next = t;
+            }
+            HIP_TRY(launch_small_linear(xr, e->qdw, e->qdb, nullptr, nullptr, nullptr, xr_next, B, H, H, s));
+            d = xr_next;
+        }
+        HIP_TRY(launch_small_linear(d, e->p1w, e->p1b, nullptr, e->p2a, nullptr, e->hhid, B, H / 4, H, s));
+        HIP_TRY(launch_small_linear(e->hhid, e->p4w, e->p4b, nullptr, nullptr, nullptr, q_out, B, 1, H / 4, s));
+    }
+    return 0;
+}
+
+// ---- per-kernel entry points -------------------------------------------------------------------------------------
+int vtq_k_split_bf16(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t nsplit, void* stream) {
+    HIP_TRY(launch_split_bf16(src, dst, plane_stride, numel, nsplit, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t N, int32_t K,
+               int32_t nsplit, int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out_bf16,
+               int64_t o_plane, int32_t ldo, void* stream) {
+    if (epilogue < 0 || epilogue > 2) return fail("vtq_k_gemm: epilogue %d", epilogue);
+    GemmArgs a{};
+    a.A = A; a.a_plane = a_plane; a.lda = lda; a.W = W; a.w_plane = w_plane; a.M = M; a.N = N; a.K = K;
+    a.bias = bias; a.gamma = gamma; a.x = x_f32; a.out = out_bf16; a.o_plane = o_plane; a.ldo = ldo;
+    HIP_TRY(launch_gemm(a, nsplit, epilogue, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int32_t rows, int32_t H,
+                    int32_t nsplit, void* stream) {
+    HIP_TRY(launch_layernorm(x, w, b, out, o_plane, rows, H, nsplit, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int32_t nseq, int32_t S, int32_t S_pad,
+                    int32_t H, int32_t nsplit, void* stream) {
+    HIP_TRY(launch_attention(qkv, plane, out, o_plane, nseq, S, S_pad, H, nsplit, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

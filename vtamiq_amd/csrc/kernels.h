@@ -1,0 +1,64 @@
+// Host-side launch prototypes of the gfx950 kernels (internal; the public ABI is include/vtamiq_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vtq {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
+
+struct GemmArgs {
+    const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
+    const void* W; int64_t w_plane;               // bf16 planes [N, K]
+    int M, N, K;                                  // M % 256 == 0, N % 256 == 0, K % 64 == 0
+    const float* bias;                            // [N]
+    const float* gamma;                           // [N] or nullptr (EPI_RESID)
+    float* x;                                     // fp32 [*, N]: EPI_RESID in/out, EPI_EMBED out
+    void* out; int64_t o_plane; int ldo;          // bf16 planes (EPI_BIAS / EPI_BIAS_GELU)
+    const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
+    const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
+    const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
+};
+
+hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s);
+
+hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s);
+
+// patches (ref,dist) fp32 [B*N, K] each -> bf16 planes [rows_pad, K], rows >= 2*B*N zero-filled
+hipError_t launch_pack_patches(const float* ref, const float* dist, void* dst, int64_t plane, int BN, int K,
+                               int rows_pad, int nsplit, hipStream_t s);
+
+// per patch row r in [0, rows_pad): pos index, scale index, destination row in the residual stream (or -1)
+hipError_t launch_embed_index(const float* pos_ref, const float* pos_dist, const float* sc_ref, const float* sc_dist,
+                              int* pidx, int* sidx, int* row_map, int B, int N, int rows_pad, int S_pad, int T,
+                              int grid, int num_scales, hipStream_t s);
+
+// CLS (+pos row 0) and register tokens into rows [seq*S_pad, seq*S_pad + T)
+hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, int S_pad,
+                         int T, int H, hipStream_t s);
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
+                            int nsplit, hipStream_t s);
+
+hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
+                            int nsplit, hipStream_t s);
+
+// zero the padding rows of the residual stream: [seq*S_pad + S, (seq+1)*S_pad) for every sequence and [nseq*S_pad, rows_total)
+hipError_t launch_zero_pad_rows(float* x, int nseq, int S, int S_pad, int H, int rows_total, hipStream_t s);
+
+// copy token rows (first T rows of each sequence) of x into trace[nseq][T][H]
+hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, int S_pad, int T, int H, hipStream_t s);
+
+// d[b] = gamma * (LN(x[row(b)]) - LN(x[row(B+b)]))  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
+hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B,
+                             int S_pad, int H, hipStream_t s);
+
+// y[b][n] = post( sum_k W[n][k] * pre(x[b][k]) + bias[n] ) (+ res[b][n]);  pre/post: optional PReLU(slope ptr)
+hipError_t launch_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope,
+                               const float* post_slope, const float* res, float* y, int B, int N, int K, hipStream_t s);
+
+// channel attention + RCAB residual: out[b] = r[b] + c[b] * sigmoid(Wu relu(Wd c[b] + bd) + bu)
+hipError_t launch_ca_residual(const float* c, const float* r, const float* Wd, const float* bd, const float* Wu,
+                              const float* bu, float* out, int B, int H, int hid, hipStream_t s);
+
+}  // namespace vtq

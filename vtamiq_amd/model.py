@@ -1,0 +1,338 @@
+"""Drop-in model callable for the reference's `VTAMIQ` (modules/vtamiq/vtamiq.py:26-119) on MI355X.
+
+Same constructor kwargs, same `state_dict()` key layout, same call
+    q, aux = model((p_ref, p_dist), (pos_ref, pos_dist), (sc_ref, sc_dist))      # aux is None, q: (B,) float32
+but `forward` runs the hand-written gfx950 engine (libvtamiq_hip.so) through its C ABI.
+
+The torch modules below are PARAMETER CONTAINERS only (they give the reference's key names and shapes and are what
+`load_state_dict`, `.to()`, `.parameters()` and `set_freeze_state` operate on); none of them is ever called.
+There is no CPU or eager fallback: a forward on CPU tensors, in train mode, or without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .spec import ModelSpec, make_spec
+
+_PRECISIONS = {"bf16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3}
+
+
+class _Params(nn.Module):
+    """A container whose forward must never run."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container of the HIP engine; call the VTAMIQ model instead")
+
+
+class _Gamma(_Params):                      # LayerScale (transformer.py:235-243)
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+
+
+class _UvPos(_Params):                      # UvPosEmbedding (transformer.py:403-415)
+    def __init__(self, n, H):
+        super().__init__()
+        self.positional_embeddings = nn.Parameter(torch.zeros(1, n, H).normal_(std=0.02))
+
+
+class _ScaleEmb(_Params):                   # ScaleEmbedding (transformer.py:385-394)
+    def __init__(self, n, H):
+        super().__init__()
+        self.scale_embeddings = nn.Parameter(torch.zeros(1, n, H).normal_(std=0.02))
+
+
+class _Embeddings(_Params):                 # Embeddings (transformer.py:458-505)
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        H, P = spec.hidden_size, spec.patch_size
+        self.patch_embeddings = nn.Conv2d(3, H, kernel_size=P, stride=P)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, H).normal_(std=0.02))
+        if spec.num_extra_tokens > 0:
+            self.extra_tokens = nn.Parameter(torch.zeros(1, spec.num_extra_tokens, H).normal_(std=0.02))
+        self.positional_embeddings = _UvPos(spec.pos_grid ** 2 + 1, H)
+        if spec.use_scale_embedding:
+            self.scale_embeddings = _ScaleEmb(spec.num_scales + 1, H)
+        self.num_tokens = spec.num_tokens
+        self.use_pos_embedding = True
+        self.use_scale_embedding = spec.use_scale_embedding
+
+
+class _Attn(_Params):                       # MultiHeadSelfAttention (transformer.py:125-146)
+    def __init__(self, H):
+        super().__init__()
+        self.query, self.key, self.value, self.out = (nn.Linear(H, H) for _ in range(4))
+
+
+class _Mlp(_Params):                        # MLP (transformer.py:197-210)
+    def __init__(self, H, M):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(H, M), nn.Linear(M, H)
+
+
+class _EncoderLayer(_Params):               # EncoderLayer (transformer.py:246-273)
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        H = spec.hidden_size
+        self.attention_norm = nn.LayerNorm(H, eps=1e-6)
+        self.ffn_norm = nn.LayerNorm(H, eps=1e-6)
+        self.ffn = _Mlp(H, spec.mlp_dim)
+        self.attn = _Attn(H)
+        if spec.use_layer_scale:
+            self.ls1, self.ls2 = _Gamma(H), _Gamma(H)
+
+
+class _Encoder(_Params):                    # Encoder (transformer.py:328-361)
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        self.encoder_norm = nn.LayerNorm(spec.hidden_size, eps=1e-6)
+        self.layers = nn.ModuleList(_EncoderLayer(spec) for _ in range(spec.num_layers))
+
+
+class _Transformer(_Params):                # VisionTransformer (transformer.py:565-626)
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        self.hidden_size = spec.hidden_size
+        self.use_layer_scale = spec.use_layer_scale
+        self.use_adapters = False
+        self.embeddings = _Embeddings(spec)
+        self.encoder = _Encoder(spec)
+        for m in self.modules():            # _init_weights (transformer.py:670-678)
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+
+def _ca_layer(H, hid):                      # CALayer.conv_du (channel_attention.py:53-62, 77-80); indices 1 and 4 hold params
+    m = _Params()
+    m.conv_du = nn.Sequential(nn.Identity(), nn.Conv1d(H, hid, 1), nn.Identity(), nn.Identity(), nn.Conv1d(hid, H, 1),
+                              nn.Identity())
+    return m
+
+
+def _rcab(H, hid):                          # RCAB.body (channel_attention.py:41-47); indices 1, 2, 4 hold params
+    m = _Params()
+    m.body = nn.Sequential(nn.Identity(), nn.PReLU(), nn.Conv1d(H, H, 1), nn.Identity(), _ca_layer(H, hid))
+    return m
+
+
+def _residual_group(H, hid, num_rcabs):     # ResidualGroup.body (channel_attention.py:18-25)
+    m = _Params()
+    m.body = nn.Sequential(*[_rcab(H, hid) for _ in range(num_rcabs)], nn.Conv1d(H, H, 1))
+    return m
+
+
+class VTAMIQ(nn.Module):
+    def __init__(self, vit_config=None, calibrate=True, diff_scale=True, num_rgs=4, num_rcabs=4, rg_path_drop=0.1,
+                 ca_reduction=8, predictor_dropout=0., return_features=False, precision: Optional[str] = None, **kwargs):
+        super().__init__()
+        for k, v in kwargs.items():         # reference only warns about unknown kwargs (vtamiq.py:49)
+            warnings.warn(f"[VTAMIQ] Unused kwarg [{k}={v}]")
+        vit_config = dict(vit_config or {})
+        self.spec = make_spec(vit_config, calibrate=calibrate, diff_scale=diff_scale, num_rgs=num_rgs,
+                              num_rcabs=num_rcabs, ca_reduction=ca_reduction)
+        spec = self.spec
+        H = spec.hidden_size
+        self.transformer = _Transformer(spec)
+        self.token_num = 0                                                   # vtamiq.py:57
+        self.diff_scale = _Gamma(H) if diff_scale else nn.Sequential()       # vtamiq.py:61
+        if calibrate:                                                        # vtamiq.py:63-69
+            self.quality_decoder = nn.Sequential(
+                *[_residual_group(H, spec.ca_hidden, num_rcabs) for _ in range(num_rgs)], nn.Conv1d(H, H, 1))
+        else:
+            self.quality_decoder = nn.Sequential()
+        self.rg_path_drop = rg_path_drop          # stochastic only in train mode, which this path rejects
+        self.predictor_dropout = predictor_dropout
+        self.q_predictor = nn.Sequential(nn.Identity(), nn.Linear(H, H // 4), nn.PReLU(), nn.Identity(),
+                                         nn.Linear(H // 4, 1))              # vtamiq.py:71-77 (Dropout slots 0 and 3)
+        self.return_features = return_features
+        precision = precision or os.environ.get("VTAMIQ_PRECISION", "bf16x3")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
+        self.precision = precision
+        self._engine = None
+        self._engine_device = None
+        self._weights_sig = None
+        self._warned_grad = False
+
+    # ---- reference surface --------------------------------------------------------------------------------
+    @property
+    def vit_hidden_size(self):                    # backbone.py:9-11
+        return self.transformer.hidden_size
+
+    @property
+    def vit_num_layers(self):                     # backbone.py:13-15
+        return len(self.transformer.encoder.layers)
+
+    def set_freeze_state(self, freeze_state, freeze_dict):
+        """requires_grad bookkeeping of vtamiq.py:81-92 / backbone.py:62-106 (host-side only; the engine never trains)."""
+        requires_grad = not freeze_state
+        fd = freeze_dict["freeze_dict_vit"]
+        freeze_all = fd is None
+        tr = self.transformer
+
+        def set_grad(m, flag):
+            for p in m.parameters():
+                p.requires_grad = flag
+
+        if freeze_all or fd["freeze_encoder"]:
+            set_grad(tr.encoder, requires_grad)
+            if not freeze_all and not fd["freeze_encoder_layerscale"] and tr.use_layer_scale:
+                for layer in tr.encoder.layers:
+                    set_grad(layer.ls1, True)
+                    set_grad(layer.ls2, True)
+        if freeze_all or fd["freeze_embeddings_cls_token"]:
+            tr.embeddings.cls_token.requires_grad = requires_grad
+        if (freeze_all or fd["freeze_embeddings_extra_tokens"]) and hasattr(tr.embeddings, "extra_tokens"):
+            tr.embeddings.extra_tokens.requires_grad = requires_grad
+        if freeze_all or fd["freeze_embeddings_patch"]:
+            set_grad(tr.embeddings.patch_embeddings, requires_grad)
+        if freeze_all or fd["freeze_embeddings_pos"]:
+            set_grad(tr.embeddings.positional_embeddings, requires_grad)
+        if (freeze_all or fd["freeze_embeddings_scale"]) and tr.embeddings.use_scale_embedding:
+            set_grad(tr.embeddings.scale_embeddings, requires_grad)
+        if freeze_dict["freeze_quality_decoder"]:
+            set_grad(self.quality_decoder, requires_grad)
+        if freeze_dict["freeze_q_predictor"]:
+            set_grad(self.q_predictor, requires_grad)
+
+    # ---- engine management --------------------------------------------------------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _release_engine(self):
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            _lib.load().vtq_destroy(eng)
+        self.__dict__["_engine"] = None
+        self.__dict__["_weights_sig"] = None
+
+    def __del__(self):
+        try:
+            self._release_engine()
+        except Exception:           # interpreter shutdown
+            pass
+
+    def refresh_weights(self):
+        """Force a re-pack of the parameters into the engine on the next forward."""
+        self._weights_sig = None
+
+    def _ensure_engine(self, device: torch.device):
+        lib = _lib.load()
+        if self._engine is not None and self._engine_device != device:
+            self._release_engine()
+        if self._engine is None:
+            s = self.spec
+            cfg = _lib.VtqConfig(
+                hidden_size=s.hidden_size, mlp_dim=s.mlp_dim, num_heads=s.num_heads, num_layers=s.num_layers,
+                patch_dim=s.patch_dim, pos_grid=s.pos_grid, num_extra_tokens=s.num_extra_tokens,
+                num_scales=s.num_scales if s.use_scale_embedding else 0, use_layer_scale=int(s.use_layer_scale),
+                calibrate=int(s.calibrate), diff_scale=int(s.diff_scale), num_rgs=s.num_rgs, num_rcabs=s.num_rcabs,
+                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.precision])
+            h = C.c_void_p()
+            _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
+            self._engine, self._engine_device = h, device
+            self._weights_sig = None
+        sig = self._signature()
+        if sig != self._weights_sig:
+            sd = self.state_dict()
+            names = [k for k, _, _ in self.spec.state_layout()]
+            missing = [k for k in names if k not in sd]
+            if missing:
+                raise RuntimeError(f"state_dict is missing {missing[:3]}...")
+            keep = []
+            descs = (_lib.VtqTensorDesc * len(names))()
+            for i, k in enumerate(names):
+                t = sd[k].detach()
+                if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.to(device=device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                descs[i] = _lib.VtqTensorDesc(k.encode(), t.data_ptr(), t.numel())
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.vtq_load_weights(self._engine, descs, len(names), stream))
+            self._weights_sig = sig
+        return lib
+
+    def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameters are replaced
+        self._weights_sig = None
+        return super()._apply(fn, *a, **k)
+
+    # ---- the hot path ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _prep(t: torch.Tensor, device) -> torch.Tensor:
+        if t.device != device:
+            raise ValueError(f"all inputs must live on {device}, got {t.device}")
+        if t.dtype != torch.float32:
+            t = t.float()                     # the loader hands everything over as f32 (train.py:254-255)
+        return t if t.is_contiguous() else t.contiguous()
+
+    def forward(self, patches, pos, scales, _trace: Optional[torch.Tensor] = None):
+        if self.training:
+            raise NotImplementedError(
+                "the MI355X engine implements the eval/no-grad forward only (Dropout/DropPath of vtamiq.py:72-75 and "
+                "channel_attention.py:26-29 are train-time stochastic; backward is out of scope): call model.eval()")
+        patches_ref, patches_dist = patches
+        pos_ref, pos_dist = pos
+        scales_ref, scales_dist = scales
+        device = patches_ref.device
+        if device.type != "cuda":
+            raise RuntimeError("VTAMIQ (vtamiq_amd) runs on an MI355X only: move the model and inputs to 'cuda'. "
+                               "There is no CPU fallback on the product path.")
+        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
+            warnings.warn("vtamiq_amd.VTAMIQ.forward returns scores without an autograd graph (inference engine)")
+            self._warned_grad = True
+        if patches_ref.dim() != 5 or patches_ref.shape != patches_dist.shape:
+            raise ValueError(f"patches must be two (B,N,3,P,P) tensors, got {tuple(patches_ref.shape)} / {tuple(patches_dist.shape)}")
+        B, N, Cc, P, P2 = patches_ref.shape
+        if (Cc, P, P2) != (3, self.spec.patch_size, self.spec.patch_size):
+            raise ValueError(f"patch shape {(Cc, P, P2)} != (3,{self.spec.patch_size},{self.spec.patch_size})")
+        if tuple(pos_ref.shape) != (B, N, 2) or tuple(pos_dist.shape) != (B, N, 2):
+            raise ValueError("pos must be two (B,N,2) tensors")
+        use_scales = self.spec.use_scale_embedding
+        if use_scales:
+            if scales_ref is None or scales_dist is None:
+                raise ValueError("Model uses scale embedding but scales is passed as None.")   # transformer.py:547-548
+            if scales_ref.numel() != B * N or scales_dist.numel() != B * N:
+                raise ValueError("scales must be two (B,N) tensors")
+        with torch.cuda.device(device):
+            lib = self._ensure_engine(device)
+            pr, pd = self._prep(patches_ref, device), self._prep(patches_dist, device)
+            qr, qd = self._prep(pos_ref, device), self._prep(pos_dist, device)
+            sr = self._prep(scales_ref, device) if use_scales else None
+            sdist = self._prep(scales_dist, device) if use_scales else None
+            q = torch.empty(B, device=device, dtype=torch.float32)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            if _trace is not None:
+                _lib.check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
+            try:
+                _lib.check(lib.vtq_forward(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
+                                           sr.data_ptr() if use_scales else None, sdist.data_ptr() if use_scales else None,
+                                           B, N, q.data_ptr(), stream))
+            finally:
+                if _trace is not None:
+                    lib.vtq_set_token_trace(self._engine, None)
+        return q, None
+
+    # ---- measurement helpers (bench.py) ---------------------------------------------------------------------
+    def profile_enable(self, classes):
+        mask = 0
+        for c in classes:
+            mask |= 1 << _lib.KERNEL_CLASSES.index(c)
+        _lib.check(_lib.load().vtq_profile_enable(self._engine, mask))
+
+    def profile_collect(self):
+        n = len(_lib.KERNEL_CLASSES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(_lib.load().vtq_profile_collect(self._engine, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
+
+    def workspace_bytes(self, B, N):
+        return int(_lib.load().vtq_workspace_bytes(self._engine, B, N)) if self._engine is not None else 0
