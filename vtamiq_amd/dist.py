@@ -22,7 +22,7 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_scores(q_local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
     """All ranks receive q[global_batch] in global pair order.  Uneven shards are padded to the largest shard so the
     collective stays a single fixed-size all-gather."""
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     if world == 1:
         return q_local
     per = -(-global_batch // world)
