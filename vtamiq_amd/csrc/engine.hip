@@ -232,7 +232,7 @@ int reserve(vtq_engine* e, int B, int N) {
         dev_alloc(e, &e->big, (size_t)e->big_plane * 2 * e->npl, true) ||
         dev_alloc(e, (void**)&e->pidx, (size_t)g.P_pad * 4, true) || dev_alloc(e, (void**)&e->sidx, (size_t)g.P_pad * 4, true) ||
         dev_alloc(e, (void**)&e->row_map, (size_t)g.P_pad * 4, true) ||
-        dev_alloc(e, (void**)&e->hhid, (size_t)nB * (H / 4) * 4, true))
+        dev_alloc(e, (void**)&e->hhid, (size_t)nB * H * 4, true))
         return 1;
     for (int i = 0; i < 5; ++i)
         if (dev_alloc(e, (void**)&e->hb[i], (size_t)nB * H * 4, true)) return 1;
@@ -446,7 +446,7 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
                 float* yo = y0;
                 for (auto& r : R.rcabs) {
                     HIP_TRY(launch_small_linear(y, r.w, r.b, r.slope, nullptr, nullptr, cb, B, H, H, s));
-                    HIP_TRY(launch_ca_residual(cb, y, r.wd, r.bd, r.wu, r.bu, yo, B, H, c.ca_hidden, s));
+                    HIP_TRY(launch_ca_residual(cb, y, r.wd, r.bd, r.wu, r.bu, e->hhid, yo, B, H, c.ca_hidden, s));
                     y = yo;
                     yo = (yo == y0) ? y1 : y0;
                 }

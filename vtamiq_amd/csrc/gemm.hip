@@ -16,6 +16,8 @@
 //   * NSPLIT == 3 ("bf16x3"): A and W arrive as hi/lo bf16 planes, each product is hi*hi + hi*lo + lo*hi into the
 //     same fp32 accumulator (3 MFMAs per 4 fragment reads); BK is halved to keep the 128 KiB LDS budget.
 //   * workgroup id is remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2 (T1).
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -148,22 +150,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane holds rows m = .. + fr, columns n .. n+3 ----------------------------------------
+    // All loads of a group are issued before its first store: the compiler cannot move a load above a store through
+    // possibly-aliasing pointers, and one dependent L2 round trip per fragment would serialise 32 of them per wave.
+    float4 b4[4], g4[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 16 + fr;
-        int orow = 0;
-        int i1 = 0, i2 = 0;
-        if constexpr (EPI == EPI_EMBED) {
-            orow = p.row_map[m];
-            i1 = p.idx1[m];
-            if (p.table2) i2 = p.idx2[m];
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fq * 4;
+        b4[j] = *(const float4*)(p.bias + n);
+        if constexpr (EPI == EPI_RESID) g4[j] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
+    }
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fq * 4;
-            const float4 b4 = *(const float4*)(p.bias + n);
-            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = m0 + wm * 128 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                float v[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
                 if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -179,48 +182,460 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs p) {
                     *(bf16x4*)o = h;
                     *(bf16x4*)(o + p.o_plane) = l;
                 }
-            } else if constexpr (EPI == EPI_RESID) {
-                float* xp = p.x + m * p.N + n;
-                float4 xv = *(const float4*)xp;
-                if (p.gamma) {
-                    const float4 g4 = *(const float4*)(p.gamma + n);
-                    xv.x += g4.x * v[0]; xv.y += g4.y * v[1]; xv.z += g4.z * v[2]; xv.w += g4.w * v[3];
-                } else {
-                    xv.x += v[0]; xv.y += v[1]; xv.z += v[2]; xv.w += v[3];
+            }
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int i2 = 0; i2 < 8; i2 += 2) {
+            float4 xv[2][4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[ii][j] = *(const float4*)(p.x + (m0 + wm * 128 + (i2 + ii) * 16 + fr) * p.N + n0 + wn * 64 + j * 16 + fq * 4);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i2 + ii;
+                    float4 r = xv[ii][j];
+                    r.x += g4[j].x * (acc[i][j][0] + b4[j].x);
+                    r.y += g4[j].y * (acc[i][j][1] + b4[j].y);
+                    r.z += g4[j].z * (acc[i][j][2] + b4[j].z);
+                    r.w += g4[j].w * (acc[i][j][3] + b4[j].w);
+                    *(float4*)(p.x + (m0 + wm * 128 + i * 16 + fr) * p.N + n0 + wn * 64 + j * 16 + fq * 4) = r;
                 }
-                *(float4*)xp = xv;
-            } else {  // EPI_EMBED
-                if (orow >= 0) {
-                    const float4 t1 = *(const float4*)(p.table1 + (int64_t)i1 * p.N + n);
-                    float4 r4 = {v[0] + t1.x, v[1] + t1.y, v[2] + t1.z, v[3] + t1.w};
-                    if (p.table2) {
-                        const float4 t2 = *(const float4*)(p.table2 + (int64_t)i2 * p.N + n);
-                        r4.x += t2.x; r4.y += t2.y; r4.z += t2.z; r4.w += t2.w;
-                    }
-                    *(float4*)(p.x + (int64_t)orow * p.N + n) = r4;
+        }
+    } else {  // EPI_EMBED
+        int orow[8], i1[8], i2x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = m0 + wm * 128 + i * 16 + fr;
+            orow[i] = p.row_map[m];
+            i1[i] = p.idx1[m];
+            i2x[i] = p.table2 ? p.idx2[m] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 t1[4], t2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                t1[j] = *(const float4*)(p.table1 + (int64_t)i1[i] * p.N + n);
+                t2[j] = p.table2 ? *(const float4*)(p.table2 + (int64_t)i2x[i] * p.N + n) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (orow[i] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                    float4 r = {acc[i][j][0] + b4[j].x + t1[j].x + t2[j].x, acc[i][j][1] + b4[j].y + t1[j].y + t2[j].y,
+                                acc[i][j][2] + b4[j].z + t1[j].z + t2[j].z, acc[i][j][3] + b4[j].w + t1[j].w + t2[j].w};
+                    *(float4*)(p.x + (int64_t)orow[i] * p.N + n) = r;
                 }
             }
         }
     }
 }
 
+
+// =====================================================================================================================
+// Variant 2: 4-phase ping-pong schedule (after the "256^2 8-phase template", cdna_hip_programming.md section 5).
+//
+//   * the 8 waves form two groups (waves 0-3 / 4-7 = the two waves of every SIMD); the second group runs one barrier
+//     behind, so while one wave of a SIMD issues its 16 (24) MFMAs the other issues its LDS reads and LDS-DMA;
+//   * a K tile is 4 half-tile regions (A rows 0-127 | 128-255, W rows 0-127 | 128-255); every wave owns 64 rows of EACH
+//     A half and 32 columns of EACH W half, so phase (mh, nh) touches exactly one A region and one W region:
+//        phase 1: read A0 + B0, MFMA quadrant (0,0)      phase 3: read A1,      MFMA (1,1)
+//        phase 2: read B1,      MFMA (0,1)               phase 4: (B0 kept),    MFMA (1,0)
+//     which frees A0/B0 after phase 1, B1 after phase 2, A1 after phase 3: each region is re-staged two phases after its
+//     last read (WAR rule), one half-tile per phase, issue order A0,B0,B1,A1 per tile: a 6-half-tile-deep DMA pipeline
+//     across two K-tile buffers with a COUNTED vmcnt (never 0 in the steady state) and raw s_barrier;
+//   * a half-tile is waited for (vmcnt) in the phase BEFORE the one that reads it (RAW rule: the other waves' pieces
+//     are only known to have landed after a barrier that follows THEIR wait).
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// allow `inflight` half-tiles (2 DMA instructions each) to stay in flight
+__device__ __forceinline__ void wait_inflight(int inflight) {
+    if (inflight >= 4) wait_vm<8>();
+    else if (inflight == 3) wait_vm<6>();
+    else if (inflight == 2) wait_vm<4>();
+    else if (inflight == 1) wait_vm<2>();
+    else wait_vm<0>();
+}
+
+template <int NSPLIT, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int BK = (NSPLIT == 1) ? 64 : 32;
+    constexpr int ROWB = BK * 2;
+    constexpr int REG_B = 16384;                    // one half-tile region (all planes)
+    constexpr int BUF_B = 4 * REG_B;                // one K tile: regions in issue order A0, B0, B1, A1
+    constexpr int NFA = 8, NFB = 4;                 // fragments per phase read: A 4 mi x (2 ks | 2 planes), B 2 ni x (..)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int ntn = p.N / BN, ntm = p.M / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;
+    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;
+    const int nkt = p.K / BK;
+    const int nseq = 4 * nkt;
+
+    // ---- DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B) -----------------
+    int64_t a_off[2], w_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if constexpr (NSPLIT == 1) {
+            const int slot = r * 512 + tid;
+            const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);
+            a_off[r] = (int64_t)row * p.lda + c * 8;
+            w_off[r] = (int64_t)row * p.K + c * 8;
+        } else {                                     // round == plane
+            const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);
+            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;
+            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;
+        }
+    }
+    // region r of sequence index s = 4*kt + r: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
+    auto stage_seq = [&](int s, int r /* == s & 3, compile-time at every call site */) {
+        if constexpr (DBG & 1) return;
+        if (s >= nseq) return;
+        const int kt = s >> 2;
+        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
+        const bool isA = (r == 0 || r == 3);
+        const int half = (r >= 2) ? 1 : 0;
+        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;
+        glds16(base + (isA ? a_off[0] : w_off[0]), dst);
+        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);
+    };
+
+    // ---- fragment read offsets inside a region ------------------------------------------------------------
+    // f = mi*2 + x (A) / ni*2 + x (B), x = k-step (NSPLIT 1) or plane (NSPLIT 3)
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        if constexpr (NSPLIT == 1) {
+            const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;
+            a_rd[x] = (wr * 64 + fr) * ROWB + ch;
+            b_rd[x] = (wc * 32 + fr) * ROWB + ch;
+        } else {
+            const int ch = (fq ^ swz<32>(fr)) << 4;
+            a_rd[x] = x * 8192 + (wr * 64 + fr) * ROWB + ch;
+            b_rd[x] = x * 8192 + (wc * 32 + fr) * ROWB + ch;
+        }
+    }
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[NFA] = {}, fb0[NFB] = {}, fb1[NFB] = {};
+    auto read_a = [&](const char* reg) {
+        if constexpr (DBG & 2) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 16 * ROWB);
+    };
+    auto read_b = [&](const char* reg, bf16x8 (&fb)[NFB]) {
+        if constexpr (DBG & 2) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const bf16x8*)(reg + b_rd[x] + j * 16 * ROWB);
+    };
+    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&fb)[NFB]) {
+        if constexpr (DBG & 4) {
+#pragma unroll
+            for (int i = 0; i < NFA; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) asm volatile("" ::"v"(fb[i]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (NSPLIT == 1) {
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j], 0, 0, 0);
+                } else {
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 1], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 0], c[i][j], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase = [LDS reads + one half-tile of DMA + counted wait] | barrier | [MFMA cluster] | barrier
+#define VTQ_PHASE_SYNC(q)                                                         \
+    wait_inflight(nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4);                       \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define VTQ_PHASE_END()                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: six half-tiles in flight, the first two landed ---------------------------------------------
+    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
+    wait_inflight(nseq >= 6 ? 4 : nseq - 2);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* buf = smem + (kt & 1) * BUF_B;
+        const int q = 4 * kt;
+        // phase 1: A0 + B0 -> quadrant (0,0); stage seq q+6 (region 2)
+        read_b(buf + 1 * REG_B, fb0);
+        read_a(buf + 0 * REG_B);
+        stage_seq(q + 6, 2);
+        VTQ_PHASE_SYNC(q)
+        mma(acc[0][0], fb0);
+        VTQ_PHASE_END()
+        // phase 2: B1 -> quadrant (0,1); stage seq q+7 (region 3)
+        read_b(buf + 2 * REG_B, fb1);
+        stage_seq(q + 7, 3);
+        VTQ_PHASE_SYNC(q + 1)
+        mma(acc[0][1], fb1);
+        VTQ_PHASE_END()
+        // phase 3: A1 -> quadrant (1,1); stage seq q+8 (region 0 of tile kt+2)
+        read_a(buf + 3 * REG_B);
+        stage_seq(q + 8, 0);
+        VTQ_PHASE_SYNC(q + 2)
+        mma(acc[1][1], fb1);
+        VTQ_PHASE_END()
+        // phase 4: quadrant (1,0) with the kept B0; stage seq q+9 (region 1 of tile kt+2)
+        stage_seq(q + 9, 1);
+        VTQ_PHASE_SYNC(q + 3)
+        mma(acc[1][0], fb0);
+        VTQ_PHASE_END()
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+#undef VTQ_PHASE_SYNC
+#undef VTQ_PHASE_END
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // acc[mh][nh][mi][ni][reg]: m = m0 + mh*128 + wr*64 + mi*16 + fr ; n = n0 + nh*128 + wc*32 + ni*16 + fq*4 + reg
+    // bf16 outputs and the fp32 residual update go through LDS (free after the main loop) so that every global access is a
+    // full row segment: one wave instruction = 2 rows x 512 B (bf16) or 1 row x 1 KiB (fp32), 16 bytes per lane.
+    if constexpr (DBG & 8) {
+        if (p.dbg == 12345) {   // never true: keeps the accumulators live
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) p.x[tid + (a * 16 + b * 8 + i * 2 + j) * 512] = acc[a][b][i][j][0] + acc[a][b][i][j][1] + acc[a][b][i][j][2] + acc[a][b][i][j][3];
+        }
+        return;
+    }
+    float4 b4[2][2], g4[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + nh * 128 + wc * 32 + ni * 16 + fq * 4;
+            b4[nh][ni] = *(const float4*)(p.bias + n);
+            if constexpr (EPI == EPI_RESID) g4[nh][ni] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
+        }
+
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        constexpr int RS = 528;                         // 256 bf16 + 16 B pad: rows stay 16-B aligned for ds_read_b128
+        constexpr int NP = (NSPLIT == 1) ? 1 : 2;
+        bf16x4 lo[(NSPLIT == 1) ? 1 : 32];
+        // pass 0: bias (+GELU), hi plane to LDS (lo kept in registers); pass 1: lo plane
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int row = mh * 128 + wr * 64 + mi * 16 + fr;
+                            const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                            const int li = ((mh * 4 + mi) * 2 + nh) * 2 + ni;
+                            bf16x4 h;
+                            if (pl == 0) {
+                                const f32x4 a = acc[mh][nh][mi][ni];
+                                const float4 bb = b4[nh][ni];
+                                float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
+                                if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                                }
+                                if constexpr (NSPLIT == 1) {
+                                    h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                                } else {
+                                    bf16x4 l;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { bf16 x, y; split2(v[e], x, y); h[e] = x; l[e] = y; }
+                                    lo[li] = l;
+                                }
+                            } else {
+                                h = lo[(NSPLIT == 1) ? 0 : li];
+                            }
+                            *(bf16x4*)(smem + row * RS + col * 2) = h;
+                        }
+            __syncthreads();
+            {
+                const int c16 = tid & 31, r0 = tid >> 5;
+                bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
+#pragma unroll
+                for (int ps = 0; ps < 16; ++ps) {
+                    const int row = ps * 16 + r0;
+                    const uint4 v = *(const uint4*)(smem + row * RS + c16 * 16);
+                    *(uint4*)(og + (int64_t)row * p.ldo) = v;
+                }
+            }
+            if (pl + 1 < NP) __syncthreads();
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+        constexpr int RS = 1040;                        // 256 fp32 + 16 B pad (odd multiple of 16: conflict-free b128 writes)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            if (mh) __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int row = wr * 64 + mi * 16 + fr;
+                        const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                        const f32x4 a = acc[mh][nh][mi][ni];
+                        const float4 bb = b4[nh][ni], gg = g4[nh][ni];
+                        const float4 v = {gg.x * (a[0] + bb.x), gg.y * (a[1] + bb.y), gg.z * (a[2] + bb.z), gg.w * (a[3] + bb.w)};
+                        *(float4*)(smem + row * RS + col * 4) = v;
+                    }
+            __syncthreads();
+            const int c16 = tid & 63, r0 = tid >> 6;
+            float* xg = p.x + (m0 + mh * 128) * p.N + n0 + c16 * 4;
+#pragma unroll
+            for (int ps4 = 0; ps4 < 16; ps4 += 4) {
+                float4 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = *(const float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (ps4 + u) * 8 + r0;
+                    const float4 d = *(const float4*)(smem + row * RS + c16 * 16);
+                    xv[u].x += d.x; xv[u].y += d.y; xv[u].z += d.z; xv[u].w += d.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *(float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N) = xv[u];
+            }
+        }
+    } else {  // EPI_EMBED: scattered rows + table gathers, once per forward: direct from registers
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t m = m0 + mh * 128 + wr * 64 + mi * 16 + fr;
+                const int orow = p.row_map[m];
+                const int i1 = p.idx1[m];
+                const int i2 = p.table2 ? p.idx2[m] : 0;
+                float4 t1[2][2], t2[2][2];
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int n = n0 + nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                        t1[nh][ni] = *(const float4*)(p.table1 + (int64_t)i1 * p.N + n);
+                        t2[nh][ni] = p.table2 ? *(const float4*)(p.table2 + (int64_t)i2 * p.N + n) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+                if (orow >= 0) {
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int n = n0 + nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                            const f32x4 a = acc[mh][nh][mi][ni];
+                            const float4 bb = b4[nh][ni];
+                            float4 r = {a[0] + bb.x + t1[nh][ni].x + t2[nh][ni].x, a[1] + bb.y + t1[nh][ni].y + t2[nh][ni].y,
+                                        a[2] + bb.z + t1[nh][ni].z + t2[nh][ni].z, a[3] + bb.w + t1[nh][ni].w + t2[nh][ni].w};
+                            *(float4*)(p.x + (int64_t)orow * p.N + n) = r;
+                        }
+                }
+            }
+    }
+}
+
 template <int NSPLIT, int EPI> hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 131072;
+    constexpr int LDS = 135168;                    // staging ring 128 KiB; epilogue images 256x528 B / 128x1040 B
     static bool configured = false;
-    auto kfn = gemm_bf16_kernel<NSPLIT, EPI>;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         configured = true;
     }
     const int nwg = (a.M / 256) * (a.N / 256);
-    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), LDS, s, a);
+    const char* v = getenv("VTQ_GEMM_VARIANT");
+    if (v && v[0] == '1') hipLaunchKernelGGL((gemm_bf16_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    else if (a.dbg && NSPLIT == 1 && EPI == EPI_BIAS) {
+        auto launch_dbg = [&](auto kfn) {
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), LDS, s, a);
+        };
+        switch (a.dbg) {
+            case 1: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 1>); break;
+            case 2: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 2>); break;
+            case 4: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 4>); break;
+            case 8: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 8>); break;
+            case 9: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 9>); break;
+            case 10: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 10>); break;
+            case 11: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 11>); break;
+            case 12: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 12>); break;
+            case 13: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 13>); break;
+            case 14: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 14>); break;
+            case 15: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 15>); break;
+            default: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 0>); break;
+        }
+    }
+    else hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a_in, int nsplit, int epilogue, hipStream_t s) {
+    GemmArgs a = a_in;
+    const char* dbg = getenv("VTQ_GEMM_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K % 64 || a.lda % 8 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
 #define VTQ_CASE(NS, EP) if (nsplit == NS && epilogue == EP) return launch_t<NS, EP>(a, s);
     VTQ_CASE(1, EPI_BIAS) VTQ_CASE(1, EPI_BIAS_GELU) VTQ_CASE(1, EPI_RESID) VTQ_CASE(1, EPI_EMBED)

@@ -13,14 +13,22 @@ namespace {
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
 
-// y[b][n] = post(sum_k W[n][k] * pre(x[b][k]) + bias[n]) + res[b][n];  K % 4 == 0, K <= 1024
+enum { HEAD_LINEAR = 0, HEAD_PRELU = 1, HEAD_RELU = 2, HEAD_GATE = 3 };
+
+// y[b][n] = epi(sum_k W[n][k] * pre(x[b][k]) + bias[n]);  K % 4 == 0, K <= 1024.
+//   grid (ceil(N/4), ceil(B/8)): one wave = one output channel n x 8 batch rows; the weight row stays in registers, the
+//   8 activation rows are independent coalesced float4 streams (8 loads in flight), one butterfly reduces all 8 sums.
+//   epi: LINEAR v (+ res[b][n]) | PRELU prelu(v, *slope) | RELU max(v,0) | GATE res[b][n] + aux[b][n] * sigmoid(v)
+template <int EPI>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ pre_slope,
                                                            const float* __restrict__ post_slope, const float* __restrict__ res,
-                                                           float* __restrict__ y, int B, int N, int K) {
+                                                           const float* __restrict__ aux, float* __restrict__ y, int B, int N,
+                                                           int K) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
+    const int b0 = blockIdx.y * 8;
     const int K4 = K >> 2;
     float4 w[4];
 #pragma unroll
@@ -30,66 +38,39 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
     }
     const bool has_pre = pre_slope != nullptr;
     const float a_pre = has_pre ? *pre_slope : 0.f;
-    const float bn = bias[n];
-    const bool has_post = post_slope != nullptr;
-    const float a_post = has_post ? *post_slope : 0.f;
-    for (int b = 0; b < B; ++b) {
+    float acc[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        const int b = (b0 + bb < B) ? b0 + bb : B - 1;
         const float4* xr = (const float4*)(x + (int64_t)b * K);
-        float acc = 0.f;
+        float a = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
             if (idx < K4) {
                 float4 v = xr[idx];
                 if (has_pre) { v.x = prelu(v.x, a_pre); v.y = prelu(v.y, a_pre); v.z = prelu(v.z, a_pre); v.w = prelu(v.w, a_pre); }
-                acc += (w[i].x * v.x + w[i].y * v.y) + (w[i].z * v.z + w[i].w * v.w);
+                a += (w[i].x * v.x + w[i].y * v.y) + (w[i].z * v.z + w[i].w * v.w);
             }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float v = acc + bn;
-            if (has_post) v = prelu(v, a_post);
-            if (res) v += res[(int64_t)b * N + n];
-            y[(int64_t)b * N + n] = v;
-        }
+        acc[bb] = a;
     }
-}
-
-// RCAB tail (channel_attention.py:49-50, 82-86): out = r + c * sigmoid(Wu relu(Wd c + bd) + bu); one workgroup per sample.
-__global__ __launch_bounds__(256) void ca_residual_kernel(const float* __restrict__ c, const float* __restrict__ r,
-                                                          const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                          const float* __restrict__ Wu, const float* __restrict__ bu,
-                                                          float* __restrict__ out, int H, int hid) {
-    __shared__ __attribute__((aligned(16))) float cs[1024];
-    __shared__ __attribute__((aligned(16))) float ts[256];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* cb = c + (int64_t)b * H;
-    for (int i = tid; i < H; i += 256) cs[i] = cb[i];
-    __syncthreads();
-    const int H4 = H >> 2;
-    for (int j = wave; j < hid; j += 4) {
-        const float4* wr = (const float4*)(Wd + (int64_t)j * H);
-        float acc = 0.f;
-        for (int idx = lane; idx < H4; idx += 64) {
-            const float4 wv = wr[idx];
-            const float4 xv = ((const float4*)cs)[idx];
-            acc += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) ts[j] = fmaxf(acc + bd[j], 0.f);
-    }
-    __syncthreads();
-    const int hid4 = hid >> 2;
-    for (int n = tid; n < H; n += 256) {
-        const float4* wr = (const float4*)(Wu + (int64_t)n * hid);
-        float acc = 0.f;
-        for (int idx = 0; idx < hid4; ++idx) {
-            const float4 wv = wr[idx];
-            const float4 tv = ((const float4*)ts)[idx];
-            acc += (wv.x * tv.x + wv.y * tv.y) + (wv.z * tv.z + wv.w * tv.w);
-        }
-        const float wgt = 1.0f / (1.0f + expf(-(acc + bu[n])));
-        out[(int64_t)b * H + n] = r[(int64_t)b * H + n] + cs[n] * wgt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) acc[bb] += __shfl_xor(acc[bb], o, 64);
+    float mine = acc[0];
+#pragma unroll
+    for (int bb = 1; bb < 8; ++bb) mine = (lane == bb) ? acc[bb] : mine;
+    const int b = b0 + lane;
+    if (lane < 8 && b < B) {
+        float v = mine + bias[n];
+        const int64_t o = (int64_t)b * N + n;
+        if constexpr (EPI == HEAD_PRELU) v = prelu(v, *post_slope);
+        else if constexpr (EPI == HEAD_RELU) v = fmaxf(v, 0.f);
+        else if constexpr (EPI == HEAD_GATE) v = res[o] + aux[o] * (1.0f / (1.0f + expf(-v)));
+        else if (res) v += res[o];
+        y[o] = v;
     }
 }
 
@@ -98,14 +79,21 @@ __global__ __launch_bounds__(256) void ca_residual_kernel(const float* __restric
 hipError_t launch_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope,
                                const float* post_slope, const float* res, float* y, int B, int N, int K, hipStream_t s) {
     if (K % 4 || K > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, W, bias, pre_slope, post_slope, res, y, B, N, K);
+    const dim3 g((N + 3) / 4, (B + 7) / 8), blk(256);
+    if (post_slope) hipLaunchKernelGGL(small_linear_kernel<HEAD_PRELU>, g, blk, 0, s, x, W, bias, pre_slope, post_slope, res, nullptr, y, B, N, K);
+    else hipLaunchKernelGGL(small_linear_kernel<HEAD_LINEAR>, g, blk, 0, s, x, W, bias, pre_slope, post_slope, res, nullptr, y, B, N, K);
     return hipGetLastError();
 }
 
+// RCAB tail (channel_attention.py:49-50, 82-86): out = r + c * sigmoid(Wu relu(Wd c + bd) + bu), t = scratch [B, hid]
 hipError_t launch_ca_residual(const float* c, const float* r, const float* Wd, const float* bd, const float* Wu, const float* bu,
-                              float* out, int B, int H, int hid, hipStream_t s) {
-    if (H > 1024 || H % 4 || hid > 256 || hid % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ca_residual_kernel, dim3(B), dim3(256), 0, s, c, r, Wd, bd, Wu, bu, out, H, hid);
+                              float* t, float* out, int B, int H, int hid, hipStream_t s) {
+    if (H > 1024 || H % 4 || hid > 1024 || hid % 4) return hipErrorInvalidValue;
+    const dim3 blk(256);
+    hipLaunchKernelGGL(small_linear_kernel<HEAD_RELU>, dim3((hid + 3) / 4, (B + 7) / 8), blk, 0, s, c, Wd, bd, nullptr, nullptr, nullptr,
+                       nullptr, t, B, hid, H);
+    hipLaunchKernelGGL(small_linear_kernel<HEAD_GATE>, dim3((H + 3) / 4, (B + 7) / 8), blk, 0, s, t, Wu, bu, nullptr, nullptr, r, c, out,
+                       B, H, hid);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ struct GemmArgs {
     const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
     const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
     const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
+    int dbg;                                      // diagnostics only (VTQ_GEMM_DBG): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s);
@@ -59,6 +60,6 @@ hipError_t launch_small_linear(const float* x, const float* W, const float* bias
 
 // channel attention + RCAB residual: out[b] = r[b] + c[b] * sigmoid(Wu relu(Wd c[b] + bd) + bu)
 hipError_t launch_ca_residual(const float* c, const float* r, const float* Wd, const float* bd, const float* Wu,
-                              const float* bu, float* out, int B, int H, int hid, hipStream_t s);
+                              const float* bu, float* t, float* out, int B, int H, int hid, hipStream_t s);
 
 }  // namespace vtq
