@@ -16,7 +16,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libvtamiq_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "head.hip", "engine.hip"]
 DEPS = ["dev_common.h", "kernels.h", os.path.join("..", "..", "include", "vtamiq_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (no v_accvgpr_read/write shuffles around the softmax)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

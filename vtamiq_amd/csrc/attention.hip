@@ -36,10 +36,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.y;
+    // 1-D grid, XCD-aware: the q-blocks of one (sequence, head) re-read the same K/V, so they must share an L2.
+    // Blocks are dealt round-robin over the 8 XCDs; remap so each XCD owns a contiguous range of work ids (bijective).
+    const int nqb = (S_pad + 127) / 128, nh = H / 64;
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7, idx = wid >> 3;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int qb = wid % nqb;
+    const int head = (wid / nqb) % nh;
+    const int seq = wid / (nqb * nh);
     const int ld = 3 * H;
-    const int64_t row0 = (int64_t)blockIdx.z * S_pad;
-    const int q_row = blockIdx.x * 128 + wave * 32 + c;
+    const int64_t row0 = (int64_t)seq * S_pad;
+    const int q_row = qb * 128 + wave * 32 + c;
 
     // ---- Q fragments: B operand of S^T = K Q^T, element j <-> d = 16t + 8hh + j ------------------------------
     bf16x8 qf[NPL][4];
@@ -100,13 +110,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int off = kb * 32 * 128 + k_rd + (((2 * tt + hh) ^ k_sw) << 4);
                 const bf16x8 kf = *(const bf16x8*)(sk + off);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], tt == 0 ? zero16 : sacc[kb], 0, 0, 0);
                 if constexpr (NSPLIT == 3) {
                     const bf16x8 kl = *(const bf16x8*)(sk + TB + off);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][tt], sacc[kb], 0, 0, 0);
@@ -115,39 +124,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             }
         }
 
-        // ---- online softmax (base-2 domain) -------------------------------------------------------------------
-        const bool tail = (t == nt - 1) && (S < S_pad);
-        float mx = -INFINITY;
+        // ---- online softmax (base-2 domain; scale folded into one FMA per score) -----------------------------------
+        if ((t == nt - 1) && (S < S_pad)) {     // wave-uniform: only the last tile holds padded keys
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = sacc[kb][r] * sc;
-                if (tail) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= S) s = -INFINITY;
+                    if (key >= S) sacc[kb][r] = -INFINITY;
                 }
-                sacc[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
+        }
+        float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);       // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        const float m_new = fmaxf(m_run, mx);                                              // raw (unscaled) running max
+        const float nm = -m_new * sc;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sacc[kb][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
                 sacc[kb][r] = pv;
                 rs += pv;
             }
-        l_run = l_run * alpha + rs;
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {        // some row's max moved: rescale (exact; usually skipped)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            l_run *= alpha;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        }
+        m_run = m_new;
+        l_run += rs;
 
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q] -------------------------------------------------------------
 #pragma unroll
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s) {
     if (H % 64 || S_pad % 64 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-    const dim3 grid((S_pad + 127) / 128, H / 64, nseq), blk(256);
+    const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
     if (nsplit == 1) {
         hipLaunchKernelGGL(attention_kernel<1>, grid, blk, 2 * 64 * 128 * 2, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S,
                            S_pad, H);

@@ -31,6 +31,12 @@ template <int BK> __device__ __forceinline__ int swz(int row) {
     else return ((row >> 3) & 1) * 3;
 }
 
+// swizzle for 32-row (32x32x16) fragment reads: 128-B rows as swz<64>; 64-B rows need (row>>2)&3
+template <int BK> __device__ __forceinline__ int swzr(int row) {
+    if constexpr (BK == 64) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+}
+
 template <int NSPLIT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256;
@@ -593,6 +599,329 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     }
 }
 
+template <int NSPLIT, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int BK = (NSPLIT == 1) ? 64 : 32;
+    constexpr int ROWB = BK * 2;
+    constexpr int REG_B = 16384;                    // one half-tile region (all planes)
+    constexpr int BUF_B = 4 * REG_B;                // one K tile: regions in issue order A0, B0, B1, A1
+    constexpr int NFA = 8, NFB = 4;                 // fragments per phase read: A 4 mi x (2 ks | 2 planes), B 2 ni x (..)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 31, fq = lane >> 5;          // 32x32x16: row/col on lane&31, k-half on lane>>5
+
+    const int ntn = p.N / BN, ntm = p.M / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;
+    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;
+    const int nkt = p.K / BK;
+    const int nseq = 4 * nkt;
+
+    // ---- DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B) -----------------
+    int64_t a_off[2], w_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if constexpr (NSPLIT == 1) {
+            const int slot = r * 512 + tid;
+            const int row = slot >> 3, c = (slot & 7) ^ swzr<64>(row);
+            a_off[r] = (int64_t)row * p.lda + c * 8;
+            w_off[r] = (int64_t)row * p.K + c * 8;
+        } else {                                     // round == plane
+            const int row = tid >> 2, c = (tid & 3) ^ swzr<32>(row);
+            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;
+            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;
+        }
+    }
+    // region r of sequence index s = 4*kt + r: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
+    auto stage_seq = [&](int s, int r /* == s & 3, compile-time at every call site */) {
+        if constexpr (DBG & 1) return;
+        if (s >= nseq) return;
+        const int kt = s >> 2;
+        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
+        const bool isA = (r == 0 || r == 3);
+        const int half = (r >= 2) ? 1 : 0;
+        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;
+        glds16(base + (isA ? a_off[0] : w_off[0]), dst);
+        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);
+    };
+
+    // ---- fragment read offsets inside a region ------------------------------------------------------------
+    // f = mi*2 + x (A) / ni*2 + x (B), x = k-step (NSPLIT 1) or plane (NSPLIT 3)
+    // x = k-step (4 for NSPLIT 1) | plane*2 + k-step (NSPLIT 3)
+    int a_rd[4], b_rd[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        if constexpr (NSPLIT == 1) {
+            const int ch = ((x * 2 + fq) ^ swzr<64>(fr)) << 4;
+            a_rd[x] = (wr * 64 + fr) * ROWB + ch;
+            b_rd[x] = (wc * 32 + fr) * ROWB + ch;
+        } else {
+            const int ch = (((x & 1) * 2 + fq) ^ swzr<32>(fr)) << 4;
+            a_rd[x] = (x >> 1) * 8192 + (wr * 64 + fr) * ROWB + ch;
+            b_rd[x] = (x >> 1) * 8192 + (wc * 32 + fr) * ROWB + ch;
+        }
+    }
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
+
+    bf16x8 fa[NFA] = {}, fb0[NFB] = {}, fb1[NFB] = {};
+    auto read_a = [&](const char* reg) {
+        if constexpr (DBG & 2) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) fa[i * 4 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 32 * ROWB);
+    };
+    auto read_b = [&](const char* reg, bf16x8 (&fb)[NFB]) {
+        if constexpr (DBG & 2) return;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fb[x] = *(const bf16x8*)(reg + b_rd[x]);
+    };
+    auto mma = [&](f32x16 (&c)[2], const bf16x8 (&fb)[NFB]) {
+        if constexpr (DBG & 4) {
+#pragma unroll
+            for (int i = 0; i < NFA; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int i = 0; i < NFB; ++i) asm volatile("" ::"v"(fb[i]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (NSPLIT == 1) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + x], c[i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {       // k-step; planes: fb[x] hi, fb[2+x] lo
+                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + x], c[i], 0, 0, 0);
+                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + 2 + x], c[i], 0, 0, 0);
+                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2 + x], fa[i * 4 + x], c[i], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase = [LDS reads + one half-tile of DMA + counted wait] | barrier | [MFMA cluster] | barrier
+#define VTQ_PHASE_SYNC(q)                                                         \
+    wait_inflight(nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4);                       \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define VTQ_PHASE_END()                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: six half-tiles in flight, the first two landed ---------------------------------------------
+    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
+    wait_inflight(nseq >= 6 ? 4 : nseq - 2);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* buf = smem + (kt & 1) * BUF_B;
+        const int q = 4 * kt;
+        // phase 1: A0 + B0 -> quadrant (0,0); stage seq q+6 (region 2)
+        read_b(buf + 1 * REG_B, fb0);
+        read_a(buf + 0 * REG_B);
+        stage_seq(q + 6, 2);
+        VTQ_PHASE_SYNC(q)
+        mma(acc[0][0], fb0);
+        VTQ_PHASE_END()
+        // phase 2: B1 -> quadrant (0,1); stage seq q+7 (region 3)
+        read_b(buf + 2 * REG_B, fb1);
+        stage_seq(q + 7, 3);
+        VTQ_PHASE_SYNC(q + 1)
+        mma(acc[0][1], fb1);
+        VTQ_PHASE_END()
+        // phase 3: A1 -> quadrant (1,1); stage seq q+8 (region 0 of tile kt+2)
+        read_a(buf + 3 * REG_B);
+        stage_seq(q + 8, 0);
+        VTQ_PHASE_SYNC(q + 2)
+        mma(acc[1][1], fb1);
+        VTQ_PHASE_END()
+        // phase 4: quadrant (1,0) with the kept B0; stage seq q+9 (region 1 of tile kt+2)
+        stage_seq(q + 9, 1);
+        VTQ_PHASE_SYNC(q + 3)
+        mma(acc[1][0], fb0);
+        VTQ_PHASE_END()
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+#undef VTQ_PHASE_SYNC
+#undef VTQ_PHASE_END
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // acc[mh][nh][mt][reg]: m = m0 + mh*128 + wr*64 + mt*32 + fr ; n = n0 + nh*128 + wc*32 + 8*(reg>>2) + 4*fq + (reg&3)
+    if constexpr (DBG & 8) {
+        if (p.dbg == 12345) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) t += acc[a][b][i][r];
+                        p.x[tid + (a * 4 + b * 2 + i) * 512] = t;
+                    }
+        }
+        return;
+    }
+    float4 b4[2][4], g4[2][4];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
+            b4[nh][g] = *(const float4*)(p.bias + n);
+            if constexpr (EPI == EPI_RESID) g4[nh][g] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
+        }
+
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        constexpr int RS = 528;
+        constexpr int NP = (NSPLIT == 1) ? 1 : 2;
+        bf16x4 lo[(NSPLIT == 1) ? 1 : 32];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int row = mh * 128 + wr * 64 + mt * 32 + fr;
+                            const int col = nh * 128 + wc * 32 + 8 * g + 4 * fq;
+                            const int li = ((mh * 2 + mt) * 2 + nh) * 4 + g;
+                            bf16x4 h;
+                            if (pl == 0) {
+                                const float4 bb = b4[nh][g];
+                                float v[4] = {acc[mh][nh][mt][4 * g + 0] + bb.x, acc[mh][nh][mt][4 * g + 1] + bb.y,
+                                              acc[mh][nh][mt][4 * g + 2] + bb.z, acc[mh][nh][mt][4 * g + 3] + bb.w};
+                                if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                                }
+                                if constexpr (NSPLIT == 1) {
+                                    h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                                } else {
+                                    bf16x4 l;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { bf16 x, y; split2(v[e], x, y); h[e] = x; l[e] = y; }
+                                    lo[li] = l;
+                                }
+                            } else {
+                                h = lo[(NSPLIT == 1) ? 0 : li];
+                            }
+                            *(bf16x4*)(smem + row * RS + col * 2) = h;
+                        }
+            __syncthreads();
+            {
+                const int c16 = tid & 31, r0 = tid >> 5;
+                bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
+#pragma unroll
+                for (int ps = 0; ps < 16; ++ps) {
+                    const int row = ps * 16 + r0;
+                    const uint4 v = *(const uint4*)(smem + row * RS + c16 * 16);
+                    *(uint4*)(og + (int64_t)row * p.ldo) = v;
+                }
+            }
+            if (pl + 1 < NP) __syncthreads();
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+        constexpr int RS = 1040;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            if (mh) __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = wr * 64 + mt * 32 + fr;
+                        const int col = nh * 128 + wc * 32 + 8 * g + 4 * fq;
+                        const float4 bb = b4[nh][g], gg = g4[nh][g];
+                        const float4 v = {gg.x * (acc[mh][nh][mt][4 * g + 0] + bb.x), gg.y * (acc[mh][nh][mt][4 * g + 1] + bb.y),
+                                          gg.z * (acc[mh][nh][mt][4 * g + 2] + bb.z), gg.w * (acc[mh][nh][mt][4 * g + 3] + bb.w)};
+                        *(float4*)(smem + row * RS + col * 4) = v;
+                    }
+            __syncthreads();
+            const int c16 = tid & 63, r0 = tid >> 6;
+            float* xg = p.x + (m0 + mh * 128) * p.N + n0 + c16 * 4;
+#pragma unroll
+            for (int ps4 = 0; ps4 < 16; ps4 += 4) {
+                float4 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = *(const float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (ps4 + u) * 8 + r0;
+                    const float4 d = *(const float4*)(smem + row * RS + c16 * 16);
+                    xv[u].x += d.x; xv[u].y += d.y; xv[u].z += d.z; xv[u].w += d.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *(float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N) = xv[u];
+            }
+        }
+    } else {  // EPI_EMBED
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int64_t m = m0 + mh * 128 + wr * 64 + mt * 32 + fr;
+                const int orow = p.row_map[m];
+                const int i1 = p.idx1[m];
+                const int i2 = p.table2 ? p.idx2[m] : 0;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float4 t1[4], t2[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
+                        t1[g] = *(const float4*)(p.table1 + (int64_t)i1 * p.N + n);
+                        t2[g] = p.table2 ? *(const float4*)(p.table2 + (int64_t)i2 * p.N + n) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (orow >= 0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
+                            const float4 bb = b4[nh][g];
+                            float4 r = {acc[mh][nh][mt][4 * g + 0] + bb.x + t1[g].x + t2[g].x, acc[mh][nh][mt][4 * g + 1] + bb.y + t1[g].y + t2[g].y,
+                                        acc[mh][nh][mt][4 * g + 2] + bb.z + t1[g].z + t2[g].z, acc[mh][nh][mt][4 * g + 3] + bb.w + t1[g].w + t2[g].w};
+                            *(float4*)(p.x + (int64_t)orow * p.N + n) = r;
+                        }
+                    }
+                }
+            }
+    }
+}
+
 template <int NSPLIT, int EPI> hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = 135168;                    // staging ring 128 KiB; epilogue images 256x528 B / 128x1040 B
     static bool configured = false;
@@ -606,6 +935,11 @@ template <int NSPLIT, int EPI> hipError_t launch_t(const GemmArgs& a, hipStream_
     const int nwg = (a.M / 256) * (a.N / 256);
     const char* v = getenv("VTQ_GEMM_VARIANT");
     if (v && v[0] == '1') hipLaunchKernelGGL((gemm_bf16_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    else if (v && v[0] == '3') {
+        static bool c3 = false;
+        if (!c3) { (void)hipFuncSetAttribute((const void*)gemm_pp32_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); c3 = true; }
+        hipLaunchKernelGGL((gemm_pp32_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    }
     else if (a.dbg && NSPLIT == 1 && EPI == EPI_BIAS) {
         auto launch_dbg = [&](auto kfn) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
