@@ -4,18 +4,28 @@
 // (modules/VisionTransformer/transformer.py:138-140,154-156,169 [QKV/out], :205-206,212-215 [MLP],
 //  :475-480,531-532 [patch embedding as GEMM]).
 //
-// Design (cdna_hip_programming.md section 5):
-//   * 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N); 128x64 per wave, 32 accumulators
-//     of mfma_f32_16x16x32_bf16 = 128 acc VGPRs).
-//   * both operands are K-contiguous (torch Linear weight layout), staged global -> LDS with 16-byte LDS-DMA
-//     (global_load_lds_dwordx4), double buffered, one barrier per K tile.
-//   * LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128 fragment reads are removed
-//     by XOR-swizzling the 16-byte chunk index on the SOURCE address and on the read (rule 21).
-//   * operands are swapped in the MFMA (W fragment as A-operand) so each lane ends up with 4 consecutive output
-//     columns of one row: bias/gamma/residual are float4 accesses and bf16 results are 8-byte stores.
-//   * NSPLIT == 3 ("bf16x3"): A and W arrive as hi/lo bf16 planes, each product is hi*hi + hi*lo + lo*hi into the
-//     same fp32 accumulator (3 MFMAs per 4 fragment reads); BK is halved to keep the 128 KiB LDS budget.
-//   * workgroup id is remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2 (T1).
+// Design (cdna_hip_programming.md section 5, "256^2 8-phase template", re-derived for this shape family):
+//   * 256x256 output tile per 512-thread workgroup, 8 waves, mfma_f32_16x16x32_bf16, 128 fp32 accumulators per lane.
+//   * Both operands are K-contiguous (torch Linear layout) and go global -> LDS by 16-byte LDS-DMA
+//     (global_load_lds_dwordx4).  The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128
+//     fragment reads are removed by XOR-swizzling the 16-byte chunk index on the SOURCE address and on the read
+//     (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * A K tile is four half-tile REGIONS (A rows 0-127 | 128-255, W rows 0-127 | 128-255).  Every wave owns 64 rows
+//     of EACH A half and 32 columns of EACH W half, so an MFMA cluster on quadrant (mh, nh) touches exactly one A
+//     region and one W region and regions are released early -> a DMA ring over two K-tile buffers that runs up to
+//     4 half-tiles ahead under a COUNTED vmcnt (never 0 in the steady state) and raw s_barrier.
+//   * Ping-pong: waves 0-3 and 4-7 (the two waves of each SIMD) run one barrier apart, so while one wave of a SIMD
+//     issues its MFMA cluster the other issues LDS reads + DMA and waits for them.
+//       2-phase schedule (default): per K tile   A: read A0,B0,B1 | 32 (x3: 48) MFMAs on quadrants (0,0),(0,1)
+//                                                 B: read A1       | 32 (x3: 48) MFMAs on quadrants (1,1),(1,0)
+//       LDS reads are retired (lgkmcnt(0)) BEFORE the phase barrier: the MFMA cluster starts right after the barrier and a
+//       region may be re-staged one phase after its last read.  Measured fixed cost per barrier interval ~250 cycles, so
+//       the longer clusters lift MFMA utilisation over the 4-phase form (16 MFMAs per interval; VTQ_GEMM_VARIANT=4).
+//   * Operands are swapped in the MFMA (W fragment as A-operand): a lane holds 4 consecutive output columns of one row.
+//   * Epilogues stage through LDS so every global access is a full row segment, 16 bytes per lane.
+//   * NSPLIT == 3 ("bf16x3"): A and W arrive as hi/lo bf16 planes; each product is hi*hi + hi*lo + lo*hi into the same fp32
+//     accumulator (3 MFMAs per 4 fragment reads); BK is 32 instead of 64 so regions keep their 16 KiB.
+//   * Workgroup ids are remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2.
 #include <cstdlib>
 
 #include "dev_common.h"
@@ -25,239 +35,12 @@ namespace vtq {
 
 namespace {
 
+// chunk swizzle of a region row: BK=64 -> 128-byte rows / 8 chunks; BK=32 -> 64-byte rows / 4 chunks (DESIGN.md "LDS swizzle")
 template <int BK> __device__ __forceinline__ int swz(int row) {
-    // BK=64: 128-byte rows, 8 chunks; BK=32: 64-byte rows, 4 chunks.  See DESIGN.md "LDS swizzle".
     if constexpr (BK == 64) return (row >> 1) & 7;
     else return ((row >> 3) & 1) * 3;
 }
 
-// swizzle for 32-row (32x32x16) fragment reads: 128-B rows as swz<64>; 64-B rows need (row>>2)&3
-template <int BK> __device__ __forceinline__ int swzr(int row) {
-    if constexpr (BK == 64) return (row >> 1) & 7;
-    else return (row >> 2) & 3;
-}
-
-template <int NSPLIT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int BK = (NSPLIT == 1) ? 64 : 32;
-    constexpr int NPL = (NSPLIT == 1) ? 1 : 2;      // bf16 planes per operand
-    constexpr int ROWB = BK * 2;                    // bytes per LDS tile row
-    constexpr int SPR = ROWB / 16;                  // 16-byte chunks per row
-    constexpr int TILE_B = BM * ROWB;               // bytes per plane tile
-    constexpr int ROUNDS = TILE_B / 8192;           // 512 threads x 16 B per round
-    constexpr int STAGE_B = TILE_B * NPL * 2;       // A planes + W planes = 64 KiB
-    constexpr int KSTEPS = BK / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    // ---- XCD-aware, bijective block -> tile map --------------------------------------------------------
-    const int ntn = p.N / BN, ntm = p.M / BM;
-    const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
-
-    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;
-    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;
-
-    // ---- per-thread DMA source offsets (elements), identical for every K tile --------------------------
-    uint32_t a_off[ROUNDS], w_off[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int slot = r * 512 + tid;
-        const int row = slot / SPR, s = slot % SPR;
-        const int c = s ^ swz<BK>(row);
-        a_off[r] = (uint32_t)(row * p.lda + c * 8);
-        w_off[r] = (uint32_t)(row * p.K + c * 8);
-    }
-
-    auto stage = [&](int kt, int buf) {
-        char* sb = smem + buf * STAGE_B + wave * 1024;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const bf16* Ap = Ag + pl * p.a_plane + kt * BK;
-            const bf16* Wp = Wg + pl * p.w_plane + kt * BK;
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                glds16(Ap + a_off[r], sb + pl * TILE_B + r * 8192);
-                glds16(Wp + w_off[r], sb + (NPL + pl) * TILE_B + r * 8192);
-            }
-        }
-    };
-
-    // ---- fragment read addresses (bytes inside a plane tile) -------------------------------------------
-    // row = w*.. + i*16 + fr ; chunk = ks*4 + fq ; swizzle depends only on fr (see swz<>): one base per ks.
-    int a_rd[KSTEPS], w_rd[KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int ch = (ks * 4 + fq) ^ swz<BK>(fr);
-        a_rd[ks] = (wm * 128 + fr) * ROWB + ch * 16;
-        w_rd[ks] = (wn * 64 + fr) * ROWB + ch * 16;
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](int buf) {
-        const char* sa = smem + buf * STAGE_B;
-        const char* sw = sa + NPL * TILE_B;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            bf16x8 wf[NPL][4];
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    wf[pl][j] = *(const bf16x8*)(sw + pl * TILE_B + w_rd[ks] + j * 16 * ROWB);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bf16x8 af[NPL];
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) af[pl] = *(const bf16x8*)(sa + pl * TILE_B + a_rd[ks] + i * 16 * ROWB);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // swapped operands: D[n_local][m_local]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[0], acc[i][j], 0, 0, 0);
-                    if constexpr (NSPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], af[0], acc[i][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- main loop: DMA of tile t+1 in flight under the MFMAs of tile t --------------------------------
-    const int nkt = p.K / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- epilogue: lane holds rows m = .. + fr, columns n .. n+3 ----------------------------------------
-    // All loads of a group are issued before its first store: the compiler cannot move a load above a store through
-    // possibly-aliasing pointers, and one dependent L2 round trip per fragment would serialise 32 of them per wave.
-    float4 b4[4], g4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fq * 4;
-        b4[j] = *(const float4*)(p.bias + n);
-        if constexpr (EPI == EPI_RESID) g4[j] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
-    }
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t m = m0 + wm * 128 + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fq * 4;
-                float v[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
-                if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                }
-                bf16* o = (bf16*)p.out + m * p.ldo + n;
-                if constexpr (NSPLIT == 1) {
-                    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *(bf16x4*)o = h;
-                } else {
-                    bf16x4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bf16 a, b; split2(v[e], a, b); h[e] = a; l[e] = b; }
-                    *(bf16x4*)o = h;
-                    *(bf16x4*)(o + p.o_plane) = l;
-                }
-            }
-        }
-    } else if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-        for (int i2 = 0; i2 < 8; i2 += 2) {
-            float4 xv[2][4];
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    xv[ii][j] = *(const float4*)(p.x + (m0 + wm * 128 + (i2 + ii) * 16 + fr) * p.N + n0 + wn * 64 + j * 16 + fq * 4);
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i2 + ii;
-                    float4 r = xv[ii][j];
-                    r.x += g4[j].x * (acc[i][j][0] + b4[j].x);
-                    r.y += g4[j].y * (acc[i][j][1] + b4[j].y);
-                    r.z += g4[j].z * (acc[i][j][2] + b4[j].z);
-                    r.w += g4[j].w * (acc[i][j][3] + b4[j].w);
-                    *(float4*)(p.x + (m0 + wm * 128 + i * 16 + fr) * p.N + n0 + wn * 64 + j * 16 + fq * 4) = r;
-                }
-        }
-    } else {  // EPI_EMBED
-        int orow[8], i1[8], i2x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t m = m0 + wm * 128 + i * 16 + fr;
-            orow[i] = p.row_map[m];
-            i1[i] = p.idx1[m];
-            i2x[i] = p.table2 ? p.idx2[m] : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float4 t1[4], t2[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fq * 4;
-                t1[j] = *(const float4*)(p.table1 + (int64_t)i1[i] * p.N + n);
-                t2[j] = p.table2 ? *(const float4*)(p.table2 + (int64_t)i2x[i] * p.N + n) : float4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (orow[i] >= 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + fq * 4;
-                    float4 r = {acc[i][j][0] + b4[j].x + t1[j].x + t2[j].x, acc[i][j][1] + b4[j].y + t1[j].y + t2[j].y,
-                                acc[i][j][2] + b4[j].z + t1[j].z + t2[j].z, acc[i][j][3] + b4[j].w + t1[j].w + t2[j].w};
-                    *(float4*)(p.x + (int64_t)orow[i] * p.N + n) = r;
-                }
-            }
-        }
-    }
-}
-
-
-// =====================================================================================================================
-// Variant 2: 4-phase ping-pong schedule (after the "256^2 8-phase template", cdna_hip_programming.md section 5).
-//
-//   * the 8 waves form two groups (waves 0-3 / 4-7 = the two waves of every SIMD); the second group runs one barrier
-//     behind, so while one wave of a SIMD issues its 16 (24) MFMAs the other issues its LDS reads and LDS-DMA;
-//   * a K tile is 4 half-tile regions (A rows 0-127 | 128-255, W rows 0-127 | 128-255); every wave owns 64 rows of EACH
-//     A half and 32 columns of EACH W half, so phase (mh, nh) touches exactly one A region and one W region:
-//        phase 1: read A0 + B0, MFMA quadrant (0,0)      phase 3: read A1,      MFMA (1,1)
-//        phase 2: read B1,      MFMA (0,1)               phase 4: (B0 kept),    MFMA (1,0)
-//     which frees A0/B0 after phase 1, B1 after phase 2, A1 after phase 3: each region is re-staged two phases after its
-//     last read (WAR rule), one half-tile per phase, issue order A0,B0,B1,A1 per tile: a 6-half-tile-deep DMA pipeline
-//     across two K-tile buffers with a COUNTED vmcnt (never 0 in the steady state) and raw s_barrier;
-//   * a half-tile is waited for (vmcnt) in the phase BEFORE the one that reads it (RAW rule: the other waves' pieces
-//     are only known to have landed after a barrier that follows THEIR wait).
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -265,206 +48,23 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// allow `inflight` half-tiles (2 DMA instructions each) to stay in flight
-__device__ __forceinline__ void wait_inflight(int inflight) {
-    if (inflight >= 4) wait_vm<8>();
-    else if (inflight == 3) wait_vm<6>();
-    else if (inflight == 2) wait_vm<4>();
-    else if (inflight == 1) wait_vm<2>();
+// allow `n` LDS-DMA instructions (2 per half-tile) to stay in flight; n is wave-uniform
+__device__ __forceinline__ void wait_dma(int n) {
+    if (n >= 8) wait_vm<8>();
+    else if (n >= 6) wait_vm<6>();
+    else if (n >= 4) wait_vm<4>();
+    else if (n >= 2) wait_vm<2>();
     else wait_vm<0>();
 }
 
-template <int NSPLIT, int EPI, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int BK = (NSPLIT == 1) ? 64 : 32;
-    constexpr int ROWB = BK * 2;
-    constexpr int REG_B = 16384;                    // one half-tile region (all planes)
-    constexpr int BUF_B = 4 * REG_B;                // one K tile: regions in issue order A0, B0, B1, A1
-    constexpr int NFA = 8, NFB = 4;                 // fragments per phase read: A 4 mi x (2 ks | 2 planes), B 2 ni x (..)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    const int ntn = p.N / BN, ntm = p.M / BM;
-    const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
-    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;
-    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;
-    const int nkt = p.K / BK;
-    const int nseq = 4 * nkt;
-
-    // ---- DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B) -----------------
-    int64_t a_off[2], w_off[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if constexpr (NSPLIT == 1) {
-            const int slot = r * 512 + tid;
-            const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);
-            a_off[r] = (int64_t)row * p.lda + c * 8;
-            w_off[r] = (int64_t)row * p.K + c * 8;
-        } else {                                     // round == plane
-            const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);
-            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;
-            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;
-        }
-    }
-    // region r of sequence index s = 4*kt + r: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
-    auto stage_seq = [&](int s, int r /* == s & 3, compile-time at every call site */) {
-        if constexpr (DBG & 1) return;
-        if (s >= nseq) return;
-        const int kt = s >> 2;
-        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
-        const bool isA = (r == 0 || r == 3);
-        const int half = (r >= 2) ? 1 : 0;
-        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;
-        glds16(base + (isA ? a_off[0] : w_off[0]), dst);
-        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);
-    };
-
-    // ---- fragment read offsets inside a region ------------------------------------------------------------
-    // f = mi*2 + x (A) / ni*2 + x (B), x = k-step (NSPLIT 1) or plane (NSPLIT 3)
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        if constexpr (NSPLIT == 1) {
-            const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;
-            a_rd[x] = (wr * 64 + fr) * ROWB + ch;
-            b_rd[x] = (wc * 32 + fr) * ROWB + ch;
-        } else {
-            const int ch = (fq ^ swz<32>(fr)) << 4;
-            a_rd[x] = x * 8192 + (wr * 64 + fr) * ROWB + ch;
-            b_rd[x] = x * 8192 + (wc * 32 + fr) * ROWB + ch;
-        }
-    }
-
-    f32x4 acc[2][2][4][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 fa[NFA] = {}, fb0[NFB] = {}, fb1[NFB] = {};
-    auto read_a = [&](const char* reg) {
-        if constexpr (DBG & 2) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 16 * ROWB);
-    };
-    auto read_b = [&](const char* reg, bf16x8 (&fb)[NFB]) {
-        if constexpr (DBG & 2) return;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const bf16x8*)(reg + b_rd[x] + j * 16 * ROWB);
-    };
-    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&fb)[NFB]) {
-        if constexpr (DBG & 4) {
-#pragma unroll
-            for (int i = 0; i < NFA; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-            for (int i = 0; i < NFB; ++i) asm volatile("" ::"v"(fb[i]));
-            return;
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (NSPLIT == 1) {
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j], 0, 0, 0);
-                } else {
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 1], c[i][j], 0, 0, 0);
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 0], c[i][j], 0, 0, 0);
-                }
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // one phase = [LDS reads + one half-tile of DMA + counted wait] | barrier | [MFMA cluster] | barrier
-#define VTQ_PHASE_SYNC(q)                                                         \
-    wait_inflight(nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4);                       \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
-    __builtin_amdgcn_sched_barrier(0);
-#define VTQ_PHASE_END()                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- prologue: six half-tiles in flight, the first two landed ---------------------------------------------
-    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
-    wait_inflight(nseq >= 6 ? 4 : nseq - 2);
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* buf = smem + (kt & 1) * BUF_B;
-        const int q = 4 * kt;
-        // phase 1: A0 + B0 -> quadrant (0,0); stage seq q+6 (region 2)
-        read_b(buf + 1 * REG_B, fb0);
-        read_a(buf + 0 * REG_B);
-        stage_seq(q + 6, 2);
-        VTQ_PHASE_SYNC(q)
-        mma(acc[0][0], fb0);
-        VTQ_PHASE_END()
-        // phase 2: B1 -> quadrant (0,1); stage seq q+7 (region 3)
-        read_b(buf + 2 * REG_B, fb1);
-        stage_seq(q + 7, 3);
-        VTQ_PHASE_SYNC(q + 1)
-        mma(acc[0][1], fb1);
-        VTQ_PHASE_END()
-        // phase 3: A1 -> quadrant (1,1); stage seq q+8 (region 0 of tile kt+2)
-        read_a(buf + 3 * REG_B);
-        stage_seq(q + 8, 0);
-        VTQ_PHASE_SYNC(q + 2)
-        mma(acc[1][1], fb1);
-        VTQ_PHASE_END()
-        // phase 4: quadrant (1,0) with the kept B0; stage seq q+9 (region 1 of tile kt+2)
-        stage_seq(q + 9, 1);
-        VTQ_PHASE_SYNC(q + 3)
-        mma(acc[1][0], fb0);
-        VTQ_PHASE_END()
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
-#undef VTQ_PHASE_SYNC
-#undef VTQ_PHASE_END
-
+// ---- shared epilogue of the ping-pong kernels -------------------------------------------------------------------------
+template <int NSPLIT, int EPI>
+__device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
+                                            int fr, int fq, int64_t m0, int n0) {
     // ---- epilogue ------------------------------------------------------------------------------------------------------
     // acc[mh][nh][mi][ni][reg]: m = m0 + mh*128 + wr*64 + mi*16 + fr ; n = n0 + nh*128 + wc*32 + ni*16 + fq*4 + reg
     // bf16 outputs and the fp32 residual update go through LDS (free after the main loop) so that every global access is a
     // full row segment: one wave instruction = 2 rows x 512 B (bf16) or 1 row x 1 KiB (fp32), 16 bytes per lane.
-    if constexpr (DBG & 8) {
-        if (p.dbg == 12345) {   // never true: keeps the accumulators live
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) p.x[tid + (a * 16 + b * 8 + i * 2 + j) * 512] = acc[a][b][i][j][0] + acc[a][b][i][j][1] + acc[a][b][i][j][2] + acc[a][b][i][j][3];
-        }
-        return;
-    }
     float4 b4[2][2], g4[2][2];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
@@ -599,377 +199,232 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     }
 }
 
-template <int NSPLIT, int EPI, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int BK = (NSPLIT == 1) ? 64 : 32;
-    constexpr int ROWB = BK * 2;
-    constexpr int REG_B = 16384;                    // one half-tile region (all planes)
-    constexpr int BUF_B = 4 * REG_B;                // one K tile: regions in issue order A0, B0, B1, A1
-    constexpr int NFA = 8, NFB = 4;                 // fragments per phase read: A 4 mi x (2 ks | 2 planes), B 2 ni x (..)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 31, fq = lane >> 5;          // 32x32x16: row/col on lane&31, k-half on lane>>5
-
-    const int ntn = p.N / BN, ntm = p.M / BM;
+// ---- common prologue of both schedules ----------------------------------------------------------------------------------
+struct Tile { int64_t m0; int n0; };
+__device__ __forceinline__ Tile tile_of_block(int M, int N) {
+    const int ntn = N / 256, ntm = M / 256;
     const int nwg = ntn * ntm;
     int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective XCD-contiguous remap
     const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
-    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;
-    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;
-    const int nkt = p.K / BK;
-    const int nseq = 4 * nkt;
+    return Tile{(int64_t)tm * 256, tn * 256};
+}
 
-    // ---- DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B) -----------------
-    int64_t a_off[2], w_off[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if constexpr (NSPLIT == 1) {
-            const int slot = r * 512 + tid;
-            const int row = slot >> 3, c = (slot & 7) ^ swzr<64>(row);
-            a_off[r] = (int64_t)row * p.lda + c * 8;
-            w_off[r] = (int64_t)row * p.K + c * 8;
-        } else {                                     // round == plane
-            const int row = tid >> 2, c = (tid & 3) ^ swzr<32>(row);
-            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;
-            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;
-        }
-    }
-    // region r of sequence index s = 4*kt + r: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
-    auto stage_seq = [&](int s, int r /* == s & 3, compile-time at every call site */) {
-        if constexpr (DBG & 1) return;
-        if (s >= nseq) return;
-        const int kt = s >> 2;
-        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
-        const bool isA = (r == 0 || r == 3);
-        const int half = (r >= 2) ? 1 : 0;
-        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;
-        glds16(base + (isA ? a_off[0] : w_off[0]), dst);
-        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);
+#define VTQ_PP_COMMON()                                                                                                  \
+    constexpr int BK = (NSPLIT == 1) ? 64 : 32;                                                                          \
+    constexpr int ROWB = BK * 2;                                                                                          \
+    constexpr int REG_B = 16384; /* one half-tile region (all planes) */                                                  \
+    constexpr int BUF_B = 4 * REG_B; /* one K tile: regions 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1 */     \
+    constexpr int NFA = 8, NFB = 4;                                                                                       \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                                           \
+    const int tid = threadIdx.x;                                                                                          \
+    const int lane = tid & 63;                                                                                            \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                            \
+    const int wr = wave >> 2, wc = wave & 3;                                                                              \
+    const int fr = lane & 15, fq = lane >> 4;                                                                             \
+    const Tile tl = tile_of_block(p.M, p.N);                                                                              \
+    const int64_t m0 = tl.m0;                                                                                             \
+    const int n0 = tl.n0;                                                                                                 \
+    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;                                                          \
+    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;                                                   \
+    const int nkt = p.K / BK;                                                                                             \
+    /* DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B; NSPLIT 3: round == plane) */       \
+    int64_t a_off[2], w_off[2];                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                       \
+        if constexpr (NSPLIT == 1) {                                                                                      \
+            const int slot = r * 512 + tid;                                                                               \
+            const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);                                                     \
+            a_off[r] = (int64_t)row * p.lda + c * 8;                                                                      \
+            w_off[r] = (int64_t)row * p.K + c * 8;                                                                        \
+        } else {                                                                                                          \
+            const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);                                                       \
+            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;                                                      \
+            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;                                                        \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    /* stage half-tile region r of K tile kt (caller guarantees kt < nkt) */                                              \
+    auto stage = [&](int kt, int r) {                                                                                     \
+        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;                                                    \
+        const bool isA = (r == 0 || r == 3);                                                                              \
+        const int half = (r >= 2) ? 1 : 0;                                                                                \
+        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;   \
+        glds16(base + (isA ? a_off[0] : w_off[0]), dst);                                                                  \
+        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);                                                           \
+    };                                                                                                                    \
+    /* fragment read offsets inside a region: x = k-step (NSPLIT 1) or plane (NSPLIT 3) */                                \
+    int a_rd[2], b_rd[2];                                                                                                 \
+    _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                                       \
+        if constexpr (NSPLIT == 1) {                                                                                      \
+            const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;                                                             \
+            a_rd[x] = (wr * 64 + fr) * ROWB + ch;                                                                         \
+            b_rd[x] = (wc * 32 + fr) * ROWB + ch;                                                                         \
+        } else {                                                                                                          \
+            const int ch = (fq ^ swz<32>(fr)) << 4;                                                                       \
+            a_rd[x] = x * 8192 + (wr * 64 + fr) * ROWB + ch;                                                              \
+            b_rd[x] = x * 8192 + (wc * 32 + fr) * ROWB + ch;                                                              \
+        }                                                                                                                 \
+    }                                                                                                                     \
+    f32x4 acc[2][2][4][2];                                                                                                \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                         \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};                \
+    bf16x8 fa[NFA], fb0[NFB], fb1[NFB];                                                                                   \
+    auto read_a = [&](const char* reg) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 16 * ROWB); \
+    };                                                                                                                    \
+    auto read_b = [&](const char* reg, bf16x8(&fb)[NFB]) {                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const bf16x8*)(reg + b_rd[x] + j * 16 * ROWB); \
+    };                                                                                                                    \
+    auto mma = [&](f32x4(&c)[4][2], const bf16x8(&fb)[NFB]) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+                if constexpr (NSPLIT == 1) {                                                                              \
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j], 0, 0, 0);    \
+                } else {                                                                                                  \
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 1], c[i][j], 0, 0, 0);    \
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
+                }                                                                                                         \
+            }                                                                                                             \
     };
 
-    // ---- fragment read offsets inside a region ------------------------------------------------------------
-    // f = mi*2 + x (A) / ni*2 + x (B), x = k-step (NSPLIT 1) or plane (NSPLIT 3)
-    // x = k-step (4 for NSPLIT 1) | plane*2 + k-step (NSPLIT 3)
-    int a_rd[4], b_rd[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        if constexpr (NSPLIT == 1) {
-            const int ch = ((x * 2 + fq) ^ swzr<64>(fr)) << 4;
-            a_rd[x] = (wr * 64 + fr) * ROWB + ch;
-            b_rd[x] = (wc * 32 + fr) * ROWB + ch;
-        } else {
-            const int ch = (((x & 1) * 2 + fq) ^ swzr<32>(fr)) << 4;
-            a_rd[x] = (x >> 1) * 8192 + (wr * 64 + fr) * ROWB + ch;
-            b_rd[x] = (x >> 1) * 8192 + (wc * 32 + fr) * ROWB + ch;
-        }
-    }
-
-    f32x16 acc[2][2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
-
-    bf16x8 fa[NFA] = {}, fb0[NFB] = {}, fb1[NFB] = {};
-    auto read_a = [&](const char* reg) {
-        if constexpr (DBG & 2) return;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) fa[i * 4 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 32 * ROWB);
-    };
-    auto read_b = [&](const char* reg, bf16x8 (&fb)[NFB]) {
-        if constexpr (DBG & 2) return;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) fb[x] = *(const bf16x8*)(reg + b_rd[x]);
-    };
-    auto mma = [&](f32x16 (&c)[2], const bf16x8 (&fb)[NFB]) {
-        if constexpr (DBG & 4) {
-#pragma unroll
-            for (int i = 0; i < NFA; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-            for (int i = 0; i < NFB; ++i) asm volatile("" ::"v"(fb[i]));
-            return;
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (NSPLIT == 1) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + x], c[i], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {       // k-step; planes: fb[x] hi, fb[2+x] lo
-                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + x], c[i], 0, 0, 0);
-                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[x], fa[i * 4 + 2 + x], c[i], 0, 0, 0);
-                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2 + x], fa[i * 4 + x], c[i], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // one phase = [LDS reads + one half-tile of DMA + counted wait] | barrier | [MFMA cluster] | barrier
-#define VTQ_PHASE_SYNC(q)                                                         \
-    wait_inflight(nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4);                       \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
-    __builtin_amdgcn_sched_barrier(0);
-#define VTQ_PHASE_END()                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
+// =====================================================================================================================
+// 2-phase ping-pong schedule (default).
+//   DMA groups in issue order: g = 2k: {A0, W0, W1} of K tile k (6 DMA instructions); g = 2k+1: {A1} of tile k (2).
+//   prologue issues groups 0,1,2; phase A(kt) issues group 2kt+3, phase B(kt) issues group 2kt+4.
+//   phase A(kt) reads A0,W0,W1 (waited for in B(kt-1) / prologue) and waits for group 2kt+1 (read in B(kt));
+//   phase B(kt) reads A1 and waits for group 2kt+2 (read in A(kt+1)).
+//   WAR: a region is read (and the read retired by lgkmcnt(0)) before its reader passes the phase barrier; the other wave
+//        group re-stages it in the NEXT phase, i.e. after that barrier.  RAW: a group is waited for by every wave one phase
+//        before the first read, and both wave groups' waits precede the barrier that opens the reading phase.
+template <int NSPLIT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
+    VTQ_PP_COMMON()
+#define VTQ_SYNC_OPEN(n_dma)                                   \
+    wait_dma(n_dma);                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    __builtin_amdgcn_s_barrier();                              \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    __builtin_amdgcn_s_setprio(1);
+#define VTQ_SYNC_CLOSE()                                       \
+    __builtin_amdgcn_s_setprio(0);                             \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    __builtin_amdgcn_s_barrier();                              \
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- prologue: six half-tiles in flight, the first two landed ---------------------------------------------
-    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
-    wait_inflight(nseq >= 6 ? 4 : nseq - 2);
+    // ---- prologue: groups 0, 1, 2 --------------------------------------------------------------------------------
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+    if (nkt > 1) { stage(1, 0); stage(1, 1); stage(1, 2); }
+    wait_dma(nkt > 1 ? 8 : 2);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
 
     for (int kt = 0; kt < nkt; ++kt) {
         const char* buf = smem + (kt & 1) * BUF_B;
+        // ---- phase A ------------------------------------------------------------------------------------------------
+        read_b(buf + 1 * REG_B, fb0);
+        read_a(buf + 0 * REG_B);
+        read_b(buf + 2 * REG_B, fb1);
+        if (kt + 1 < nkt) stage(kt + 1, 3);
+        VTQ_SYNC_OPEN(kt + 1 < nkt ? 8 : 0)
+        mma(acc[0][0], fb0);
+        mma(acc[0][1], fb1);
+        VTQ_SYNC_CLOSE()
+        // ---- phase B ------------------------------------------------------------------------------------------------
+        read_a(buf + 3 * REG_B);
+        if (kt + 2 < nkt) { stage(kt + 2, 0); stage(kt + 2, 1); stage(kt + 2, 2); }
+        VTQ_SYNC_OPEN(kt + 2 < nkt ? 8 : (kt + 1 < nkt ? 2 : 0))
+        mma(acc[1][1], fb1);
+        mma(acc[1][0], fb0);
+        VTQ_SYNC_CLOSE()
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+#undef VTQ_SYNC_OPEN
+#undef VTQ_SYNC_CLOSE
+    pp_epilogue<NSPLIT, EPI>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
+}
+
+// =====================================================================================================================
+// 4-phase ping-pong schedule (VTQ_GEMM_VARIANT=4; kept for A/B): one quadrant (16 / 24 MFMAs) per phase, half-tiles issued
+// one per phase in the order A0,W0,W1,A1, six half-tiles of lead, reads retired after the barrier.
+template <int NSPLIT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) {
+    VTQ_PP_COMMON()
+    const int nseq = 4 * nkt;
+    auto stage_seq = [&](int s, int r) { if (s < nseq) stage(s >> 2, r); };
+#define VTQ_PHASE_SYNC(q)                                                         \
+    wait_dma(2 * (nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4));                      \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_setprio(1);
+#define VTQ_PHASE_END()                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    __builtin_amdgcn_s_barrier();                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+
+    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
+    wait_dma(2 * (nseq >= 6 ? 4 : nseq - 2));
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* buf = smem + (kt & 1) * BUF_B;
         const int q = 4 * kt;
-        // phase 1: A0 + B0 -> quadrant (0,0); stage seq q+6 (region 2)
         read_b(buf + 1 * REG_B, fb0);
         read_a(buf + 0 * REG_B);
         stage_seq(q + 6, 2);
         VTQ_PHASE_SYNC(q)
         mma(acc[0][0], fb0);
         VTQ_PHASE_END()
-        // phase 2: B1 -> quadrant (0,1); stage seq q+7 (region 3)
         read_b(buf + 2 * REG_B, fb1);
         stage_seq(q + 7, 3);
         VTQ_PHASE_SYNC(q + 1)
         mma(acc[0][1], fb1);
         VTQ_PHASE_END()
-        // phase 3: A1 -> quadrant (1,1); stage seq q+8 (region 0 of tile kt+2)
         read_a(buf + 3 * REG_B);
         stage_seq(q + 8, 0);
         VTQ_PHASE_SYNC(q + 2)
         mma(acc[1][1], fb1);
         VTQ_PHASE_END()
-        // phase 4: quadrant (1,0) with the kept B0; stage seq q+9 (region 1 of tile kt+2)
         stage_seq(q + 9, 1);
         VTQ_PHASE_SYNC(q + 3)
         mma(acc[1][0], fb0);
         VTQ_PHASE_END()
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+    if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef VTQ_PHASE_SYNC
 #undef VTQ_PHASE_END
-
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
-    // acc[mh][nh][mt][reg]: m = m0 + mh*128 + wr*64 + mt*32 + fr ; n = n0 + nh*128 + wc*32 + 8*(reg>>2) + 4*fq + (reg&3)
-    if constexpr (DBG & 8) {
-        if (p.dbg == 12345) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float t = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) t += acc[a][b][i][r];
-                        p.x[tid + (a * 4 + b * 2 + i) * 512] = t;
-                    }
-        }
-        return;
-    }
-    float4 b4[2][4], g4[2][4];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
-            b4[nh][g] = *(const float4*)(p.bias + n);
-            if constexpr (EPI == EPI_RESID) g4[nh][g] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
-        }
-
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        constexpr int RS = 528;
-        constexpr int NP = (NSPLIT == 1) ? 1 : 2;
-        bf16x4 lo[(NSPLIT == 1) ? 1 : 32];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int row = mh * 128 + wr * 64 + mt * 32 + fr;
-                            const int col = nh * 128 + wc * 32 + 8 * g + 4 * fq;
-                            const int li = ((mh * 2 + mt) * 2 + nh) * 4 + g;
-                            bf16x4 h;
-                            if (pl == 0) {
-                                const float4 bb = b4[nh][g];
-                                float v[4] = {acc[mh][nh][mt][4 * g + 0] + bb.x, acc[mh][nh][mt][4 * g + 1] + bb.y,
-                                              acc[mh][nh][mt][4 * g + 2] + bb.z, acc[mh][nh][mt][4 * g + 3] + bb.w};
-                                if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                                }
-                                if constexpr (NSPLIT == 1) {
-                                    h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                                } else {
-                                    bf16x4 l;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) { bf16 x, y; split2(v[e], x, y); h[e] = x; l[e] = y; }
-                                    lo[li] = l;
-                                }
-                            } else {
-                                h = lo[(NSPLIT == 1) ? 0 : li];
-                            }
-                            *(bf16x4*)(smem + row * RS + col * 2) = h;
-                        }
-            __syncthreads();
-            {
-                const int c16 = tid & 31, r0 = tid >> 5;
-                bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
-#pragma unroll
-                for (int ps = 0; ps < 16; ++ps) {
-                    const int row = ps * 16 + r0;
-                    const uint4 v = *(const uint4*)(smem + row * RS + c16 * 16);
-                    *(uint4*)(og + (int64_t)row * p.ldo) = v;
-                }
-            }
-            if (pl + 1 < NP) __syncthreads();
-        }
-    } else if constexpr (EPI == EPI_RESID) {
-        constexpr int RS = 1040;
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
-            if (mh) __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = wr * 64 + mt * 32 + fr;
-                        const int col = nh * 128 + wc * 32 + 8 * g + 4 * fq;
-                        const float4 bb = b4[nh][g], gg = g4[nh][g];
-                        const float4 v = {gg.x * (acc[mh][nh][mt][4 * g + 0] + bb.x), gg.y * (acc[mh][nh][mt][4 * g + 1] + bb.y),
-                                          gg.z * (acc[mh][nh][mt][4 * g + 2] + bb.z), gg.w * (acc[mh][nh][mt][4 * g + 3] + bb.w)};
-                        *(float4*)(smem + row * RS + col * 4) = v;
-                    }
-            __syncthreads();
-            const int c16 = tid & 63, r0 = tid >> 6;
-            float* xg = p.x + (m0 + mh * 128) * p.N + n0 + c16 * 4;
-#pragma unroll
-            for (int ps4 = 0; ps4 < 16; ps4 += 4) {
-                float4 xv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = *(const float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int row = (ps4 + u) * 8 + r0;
-                    const float4 d = *(const float4*)(smem + row * RS + c16 * 16);
-                    xv[u].x += d.x; xv[u].y += d.y; xv[u].z += d.z; xv[u].w += d.w;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *(float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N) = xv[u];
-            }
-        }
-    } else {  // EPI_EMBED
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int64_t m = m0 + mh * 128 + wr * 64 + mt * 32 + fr;
-                const int orow = p.row_map[m];
-                const int i1 = p.idx1[m];
-                const int i2 = p.table2 ? p.idx2[m] : 0;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    float4 t1[4], t2[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
-                        t1[g] = *(const float4*)(p.table1 + (int64_t)i1 * p.N + n);
-                        t2[g] = p.table2 ? *(const float4*)(p.table2 + (int64_t)i2 * p.N + n) : float4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (orow >= 0) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int n = n0 + nh * 128 + wc * 32 + 8 * g + 4 * fq;
-                            const float4 bb = b4[nh][g];
-                            float4 r = {acc[mh][nh][mt][4 * g + 0] + bb.x + t1[g].x + t2[g].x, acc[mh][nh][mt][4 * g + 1] + bb.y + t1[g].y + t2[g].y,
-                                        acc[mh][nh][mt][4 * g + 2] + bb.z + t1[g].z + t2[g].z, acc[mh][nh][mt][4 * g + 3] + bb.w + t1[g].w + t2[g].w};
-                            *(float4*)(p.x + (int64_t)orow * p.N + n) = r;
-                        }
-                    }
-                }
-            }
-    }
+    pp_epilogue<NSPLIT, EPI>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
 }
 
 template <int NSPLIT, int EPI> hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 135168;                    // staging ring 128 KiB; epilogue images 256x528 B / 128x1040 B
+    constexpr int LDS = 135168;                    // DMA ring 128 KiB; epilogue images 256x528 B / 128x1040 B
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_pp2_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        e = hipFuncSetAttribute((const void*)gemm_pp4_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         configured = true;
     }
     const int nwg = (a.M / 256) * (a.N / 256);
     const char* v = getenv("VTQ_GEMM_VARIANT");
-    if (v && v[0] == '1') hipLaunchKernelGGL((gemm_bf16_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
-    else if (v && v[0] == '3') {
-        static bool c3 = false;
-        if (!c3) { (void)hipFuncSetAttribute((const void*)gemm_pp32_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); c3 = true; }
-        hipLaunchKernelGGL((gemm_pp32_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
-    }
-    else if (a.dbg && NSPLIT == 1 && EPI == EPI_BIAS) {
-        auto launch_dbg = [&](auto kfn) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), LDS, s, a);
-        };
-        switch (a.dbg) {
-            case 1: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 1>); break;
-            case 2: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 2>); break;
-            case 4: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 4>); break;
-            case 8: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 8>); break;
-            case 9: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 9>); break;
-            case 10: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 10>); break;
-            case 11: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 11>); break;
-            case 12: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 12>); break;
-            case 13: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 13>); break;
-            case 14: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 14>); break;
-            case 15: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 15>); break;
-            default: launch_dbg(gemm_pp_kernel<1, EPI_BIAS, 0>); break;
-        }
-    }
-    else hipLaunchKernelGGL((gemm_pp_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    if (v && v[0] == '4') hipLaunchKernelGGL((gemm_pp4_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    else hipLaunchKernelGGL((gemm_pp2_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& a_in, int nsplit, int epilogue, hipStream_t s) {
-    GemmArgs a = a_in;
-    const char* dbg = getenv("VTQ_GEMM_DBG");
-    a.dbg = dbg ? atoi(dbg) : 0;
+hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K % 64 || a.lda % 8 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
 #define VTQ_CASE(NS, EP) if (nsplit == NS && epilogue == EP) return launch_t<NS, EP>(a, s);
     VTQ_CASE(1, EPI_BIAS) VTQ_CASE(1, EPI_BIAS_GELU) VTQ_CASE(1, EPI_RESID) VTQ_CASE(1, EPI_EMBED)

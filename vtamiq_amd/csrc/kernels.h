@@ -18,7 +18,6 @@ struct GemmArgs {
     const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
     const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
     const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
-    int dbg;                                      // diagnostics only (VTQ_GEMM_DBG): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s);
