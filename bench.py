@@ -28,6 +28,16 @@ def synth_inputs_on_device(torch, spec, B, N, device, seed):
     return (ref, dist), (pos, pos.clone()), (None, None)
 
 
+def fc1_traffic(precision, B):
+    """HBM bytes per fc1 launch from the committed PMC passes (profiles/r01_gemm_fc1_traffic.json: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, collected at B=32 in separate rocprofv3 --pmc runs); scaled linearly with the batch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_fc1_traffic.json")))
+        return d[precision]["bytes_per_launch"] * (B / 32.0)
+    except Exception:
+        return None
+
+
 def effective_cores():
     """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -169,7 +179,7 @@ def main():
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": f"gemm_bf16_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1)",
                            "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                           "traffic": None, "avg_launch_ms": ms_sum / launches, "launches": int(launches),
+                           "traffic": fc1_traffic(a.precision, B), "avg_launch_ms": ms_sum / launches, "launches": int(launches),
                            "flops_per_launch": flops_launch}
     if rank == 0 and not a.no_second_mode:
         other = "bf16" if a.precision == "bf16x3" else "bf16x3"
