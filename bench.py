@@ -156,7 +156,8 @@ def main():
     dt, q, prof = run(model, a.steps, a.warmup, DOM)
     assert q.shape == (global_batch,) and bool(torch.isfinite(q).all())
     pairs_per_s = global_batch * a.steps / dt
-    f_pair = spec.flops_per_pair(N)
+    f_pair = spec.flops_per_pair(N)                      # algorithmic (SURVEY 8d / BASELINE.md)
+    f_exec = spec.flops_per_pair_executed(N, cls_prune=os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1")
     S = spec.seq_len(N)
 
     out = {
@@ -170,8 +171,9 @@ def main():
                    "numerics": a.precision,
                    "numerics_note": "bf16x3 = hi/lo bf16 operand split, 3 bf16 MFMAs per product, fp32 accumulate (meets 1e-3 "
                                     "parity); bf16 = 1 MFMA per product (throughput mode, parity ~3e-2)"},
-        "forward_mfma_frac": pairs_per_s / world * f_pair / (PEAK_BF16_TFLOPS * 1e12),
-        "flops_per_pair": f_pair,
+        # executed flops: the last layer runs Q/attention/out-proj/MLP for the CLS row only (legal: only token 0 is consumed)
+        "forward_mfma_frac": pairs_per_s / world * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+        "flops_per_pair": f_pair, "flops_per_pair_executed": f_exec,
     }
     if prof and prof[1] > 0:
         ms_sum, launches = prof
@@ -190,7 +192,7 @@ def main():
         model2 = make_model(other)
         dt2, q2, _ = run(model2, max(3, a.steps // 2), 2)
         out["other_mode"] = {"numerics": other, "value": global_batch * max(3, a.steps // 2) / dt2, "unit": "image-pairs/s",
-                             "forward_mfma_frac": global_batch * max(3, a.steps // 2) / dt2 / world * f_pair / (PEAK_BF16_TFLOPS * 1e12)}
+                             "forward_mfma_frac": global_batch * max(3, a.steps // 2) / dt2 / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)}
     else:
         q2 = None
     if rank == 0:

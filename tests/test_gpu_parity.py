@@ -131,6 +131,19 @@ def test_full_size_properties(precision):
     assert gate(q[sel].cpu().numpy(), q_ref, TOL[precision]), e
 
 
+@pytest.mark.parametrize("name", ["c1_b2_n50", "refdefault_b2_n64", "vitl_b2_n70"])
+def test_cls_pruned_last_layer_matches_full_layer(name, monkeypatch):
+    """The CLS-only tail of the last layer (cls_tail.hip) against running the full last layer (VTQ_NO_CLS_PRUNE=1)."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    with torch.no_grad():
+        q_pruned = build(kw, sd, "bf16x3")(p, ps, sc)[0].cpu().numpy()
+        monkeypatch.setenv("VTQ_NO_CLS_PRUNE", "1")
+        q_full = build(kw, sd, "bf16x3")(p, ps, sc)[0].cpu().numpy()
+    assert gate(q_pruned, g["q"], 1e-3) and gate(q_full, g["q"], 1e-3)
+    assert gate(q_pruned, q_full, 3e-4), rel_err(q_pruned, q_full)
+
+
 def test_rejects_what_the_reference_rejects():
     model, _ = _c2_model("bf16")
     p = torch.zeros(1, 8, 3, 16, 16, device=DEV)

@@ -1,0 +1,180 @@
+// Last encoder layer, CLS row only.
+//
+// VTAMIQ consumes token 0 of the encoder output and nothing else (modules/vtamiq/vtamiq.py:104-108), so in the LAST
+// EncoderLayer (modules/VisionTransformer/transformer.py:275-285) only the K/V projections need every row; the query,
+// the attention output, out-proj, LayerNorm_2 and the MLP are needed for the 2B CLS rows alone.  These kernels run that
+// 2B-row tail in fp32 activations against the packed bf16 (hi[, lo]) weight planes; results are identical in exact
+// arithmetic to running the full layer and reading row 0 (SURVEY.md 8d allows the pruning; bench reports executed flops).
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace vtq {
+namespace {
+
+// LayerNorm(eps 1e-6) of gathered fp32 rows: src row r at src + r*stride; writes ln[r][H] and optionally a copy of the row.
+template <int V4>
+__global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ src, int64_t stride, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ ln, float* __restrict__ copy,
+                                                      int rows) {
+    constexpr int H = 256 * V4;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float4* xr = (const float4*)(src + r * stride);
+    float4 v[V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i] = xr[i * 64 + lane];
+        if (copy) ((float4*)(copy + (int64_t)r * H))[i * 64 + lane] = v[i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const float4 w4 = ((const float4*)w)[i * 64 + lane], b4 = ((const float4*)b)[i * 64 + lane];
+        float4 y = {v[i].x * rstd * w4.x + b4.x, v[i].y * rstd * w4.y + b4.y, v[i].z * rstd * w4.z + b4.z, v[i].w * rstd * w4.w + b4.w};
+        ((float4*)(ln + (int64_t)r * H))[i * 64 + lane] = y;
+    }
+}
+
+enum { ROWS_PLAIN = 0, ROWS_GELU = 1, ROWS_RESID = 2 };
+
+// y[r][n] = epi(sum_k (w_hi[n][k] + w_lo[n][k]) * x[r][k] + bias[n]);  K % 256 == 0; one wave = one n x 8 rows.
+template <int NPL, int EPI>
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, const bf16* __restrict__ W, int64_t w_plane,
+                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                          const float* __restrict__ res, float* __restrict__ y, int R, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int r0 = blockIdx.y * 8;
+    const int KP = K >> 8;                        // 4-element pieces per lane
+    const bf16* wr = W + (int64_t)n * K;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int pc = 0; pc < KP; ++pc) {
+        const int idx = pc * 64 + lane;           // float4 index inside the row
+        const bf16x4 wh = ((const bf16x4*)wr)[idx];
+        float4 w4 = {(float)wh[0], (float)wh[1], (float)wh[2], (float)wh[3]};
+        if constexpr (NPL == 2) {
+            const bf16x4 wl = ((const bf16x4*)(wr + w_plane))[idx];
+            w4.x += (float)wl[0]; w4.y += (float)wl[1]; w4.z += (float)wl[2]; w4.w += (float)wl[3];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = (r0 + rr < R) ? r0 + rr : R - 1;
+            const float4 v = ((const float4*)(x + (int64_t)r * K))[idx];
+            acc[rr] += (w4.x * v.x + w4.y * v.y) + (w4.z * v.z + w4.w * v.w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] += __shfl_xor(acc[rr], o, 64);
+    float mine = acc[0];
+#pragma unroll
+    for (int rr = 1; rr < 8; ++rr) mine = (lane == rr) ? acc[rr] : mine;
+    const int r = r0 + lane;
+    if (lane < 8 && r < R) {
+        float v = mine + bias[n];
+        const int64_t o = (int64_t)r * N + n;
+        if constexpr (EPI == ROWS_GELU) v = gelu_erf(v);
+        if constexpr (EPI == ROWS_RESID) v = res[o] + (gamma ? gamma[n] : 1.0f) * v;
+        y[o] = v;
+    }
+}
+
+// attention of the single CLS query of each (sequence, head) over the S keys of the sequence; K, V from the packed bf16 planes.
+template <int NPL>
+__global__ __launch_bounds__(64) void cls_attention_kernel(const float* __restrict__ q, const bf16* __restrict__ qkv, int64_t plane,
+                                                           float* __restrict__ out, int S, int S_pad, int H) {
+    __shared__ float ps[2048];
+    const int lane = threadIdx.x;
+    const int head = blockIdx.x, seq = blockIdx.y;
+    const int ld = 3 * H;
+    const bf16* kb = qkv + ((int64_t)seq * S_pad) * ld + H + head * 64;
+    const bf16* vb = kb + H;
+    float qv[64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 t = ((const float4*)(q + (int64_t)seq * H + head * 64))[i];
+        qv[4 * i] = t.x; qv[4 * i + 1] = t.y; qv[4 * i + 2] = t.z; qv[4 * i + 3] = t.w;
+    }
+    // scores: lane owns keys lane, lane+64, ...
+    float mx = -INFINITY;
+    for (int key = lane; key < S; key += 64) {
+        const bf16* kr = kb + (int64_t)key * ld;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8 kh = ((const bf16x8*)kr)[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float kv = (float)kh[e];
+                if constexpr (NPL == 2) kv += (float)((const bf16*)(kr + plane))[c * 8 + e];
+                s += qv[c * 8 + e] * kv;
+            }
+        }
+        s *= 0.125f;
+        ps[key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int key = lane; key < S; key += 64) {
+        const float p = expf(ps[key] - mx);
+        ps[key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    // out[d = lane] = sum_key p[key] * V[key][d]
+    float o = 0.f;
+    for (int key = 0; key < S; ++key) {
+        float vv = (float)vb[(int64_t)key * ld + lane];
+        if constexpr (NPL == 2) vv += (float)vb[(int64_t)key * ld + plane + lane];
+        o += ps[key] * vv;
+    }
+    out[(int64_t)seq * H + head * 64 + lane] = o / sum;
+}
+
+}  // namespace
+
+hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
+                          hipStream_t s) {
+    const dim3 g((rows + 3) / 4), blk(256);
+    if (H == 768) hipLaunchKernelGGL(rows_ln_kernel<3>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
+    else if (H == 1024) hipLaunchKernelGGL(rows_ln_kernel<4>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int nsplit, const float* bias, const float* gamma,
+                              const float* res, float* y, int R, int N, int K, int epi, hipStream_t s) {
+    if (K % 256 || epi < 0 || epi > 2) return hipErrorInvalidValue;
+    const dim3 g((N + 3) / 4, (R + 7) / 8), blk(256);
+#define VTQ_RL(NP, EP) hipLaunchKernelGGL((rows_linear_kernel<NP, EP>), g, blk, 0, s, x, (const bf16*)W, w_plane, bias, gamma, res, y, R, N, K)
+    if (nsplit == 1) { if (epi == 0) VTQ_RL(1, 0); else if (epi == 1) VTQ_RL(1, 1); else VTQ_RL(1, 2); }
+    else { if (epi == 0) VTQ_RL(2, 0); else if (epi == 1) VTQ_RL(2, 1); else VTQ_RL(2, 2); }
+#undef VTQ_RL
+    return hipGetLastError();
+}
+
+hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
+                                int nsplit, hipStream_t s) {
+    if (S > 2048) return hipErrorInvalidValue;
+    const dim3 g(H / 64, nseq), blk(64);
+    if (nsplit == 1) hipLaunchKernelGGL(cls_attention_kernel<1>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
+    else hipLaunchKernelGGL(cls_attention_kernel<2>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
+    return hipGetLastError();
+}
+
+}  // namespace vtq

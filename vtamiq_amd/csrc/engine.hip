@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -82,6 +83,8 @@ struct vtq_engine {
     int *pidx = nullptr, *sidx = nullptr, *row_map = nullptr;
     float* hb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* hhid = nullptr;
+    float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr, *h1cls = nullptr;   // CLS-only last layer
+    bool cls_prune = true;
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
     // profiling
@@ -211,7 +214,8 @@ size_t workspace_bytes(const vtq_engine* e, int B, int N) {
     b += (size_t)g.rows_alloc * H * 2 * e->npl;           // LN / attention output planes
     b += (size_t)g.rows_alloc * Wmax * 2 * e->npl;        // qkv | mlp hidden | packed patches planes
     b += (size_t)g.P_pad * 4 * 3;                         // pos/scale indices, row map
-    b += (size_t)B * H * 4 * 5 + (size_t)B * (H / 4) * 4; // head ping-pong buffers
+    b += (size_t)B * H * 4 * 6;                           // head ping-pong buffers
+    b += (size_t)2 * B * (4 * H + e->Mdim) * 4;           // CLS-only last-layer rows
     return b;
 }
 
@@ -236,6 +240,10 @@ int reserve(vtq_engine* e, int B, int N) {
         return 1;
     for (int i = 0; i < 5; ++i)
         if (dev_alloc(e, (void**)&e->hb[i], (size_t)nB * H * 4, true)) return 1;
+    if (dev_alloc(e, (void**)&e->xcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->lncls, (size_t)2 * nB * H * 4, true) ||
+        dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->acls, (size_t)2 * nB * H * 4, true) ||
+        dev_alloc(e, (void**)&e->h1cls, (size_t)2 * nB * e->Mdim * 4, true))
+        return 1;
     // finite contents everywhere: padded rows are computed on (never consumed) and must not breed NaNs
     HIP_TRY(hipMemset(e->x, 0, (size_t)g.rows_alloc * H * 4));
     HIP_TRY(hipMemset(e->lnbuf, 0, (size_t)e->ln_plane * 2 * e->npl));
@@ -287,6 +295,7 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     e->H = c.hidden_size;
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
+    { const char* np = getenv("VTQ_NO_CLS_PRUNE"); e->cls_prune = !(np && np[0] == '1'); }
     if (build(e)) { vtq_destroy(e); return 1; }
     *out = e;
     return 0;
@@ -396,8 +405,37 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
 
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
     const int M = (int)g.M_pad;
+    const bool prune = e->cls_prune && !e->trace;      // the trace tap needs every token row of the last layer
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
+        if (prune && i == L - 1) {
+            // ---- last layer: K/V for every row, everything else for the 2B CLS rows only (cls_tail.hip) ------------
+            const int R = g.nseq;
+            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln1w, Ly.ln1b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
+            {
+                Prof p(e, s, VTQ_K_QKV);
+                GemmArgs a{};
+                a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H;
+                a.W = (const char*)Ly.wqkv + (size_t)H * H * 2; a.w_plane = Ly.pqkv;
+                a.M = M; a.N = 2 * H; a.K = H; a.bias = Ly.bqkv + H;
+                a.out = (char*)e->big + (size_t)H * 2; a.o_plane = e->big_plane; a.ldo = 3 * H;
+                HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+            }
+            {
+                Prof p(e, s, VTQ_K_ATTN);
+                HIP_TRY(launch_rows_ln(e->x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, e->lncls, e->xcls, R, H, s));
+                HIP_TRY(launch_rows_linear(e->lncls, Ly.wqkv, Ly.pqkv, ns, Ly.bqkv, nullptr, nullptr, e->qcls, R, H, H, 0, s));
+                HIP_TRY(launch_cls_attention(e->qcls, e->big, e->big_plane, e->acls, R, g.S, g.S_pad, H, ns, s));
+            }
+            {
+                Prof p(e, s, VTQ_K_OUTPROJ);
+                HIP_TRY(launch_rows_linear(e->acls, Ly.wo, Ly.po, ns, Ly.bo, Ly.g1, e->xcls, e->xcls, R, H, H, 2, s));
+            }
+            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_rows_ln(e->xcls, H, Ly.ln2w, Ly.ln2b, e->lncls, nullptr, R, H, s)); }
+            { Prof p(e, s, VTQ_K_FC1); HIP_TRY(launch_rows_linear(e->lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, e->h1cls, R, Md, H, 1, s)); }
+            { Prof p(e, s, VTQ_K_FC2); HIP_TRY(launch_rows_linear(e->h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, e->xcls, e->xcls, R, H, Md, 2, s)); }
+            break;
+        }
         { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln1w, Ly.ln1b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
         {
             Prof p(e, s, VTQ_K_QKV);
@@ -436,7 +474,8 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
     {
         Prof p(e, s, VTQ_K_HEAD);
         float* d = e->hb[0];
-        HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, g.S_pad, H, s));
+        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, 1, H, s));
+        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, g.S_pad, H, s));
         if (c.calibrate) {
             float* xr = e->hb[0];       // residual-group input
             float* xr_next = e->hb[1];

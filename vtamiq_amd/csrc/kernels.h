@@ -61,4 +61,13 @@ hipError_t launch_small_linear(const float* x, const float* W, const float* bias
 hipError_t launch_ca_residual(const float* c, const float* r, const float* Wd, const float* bd, const float* Wu,
                               const float* bu, float* t, float* out, int B, int H, int hid, hipStream_t s);
 
+// ---- CLS-only tail of the last encoder layer (cls_tail.hip) -----------------------------------------------------------
+hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
+                          hipStream_t s);
+// y[r][n] = epi(W[n] . x[r] + bias[n]) with W as bf16 planes; epi 0 plain, 1 GELU, 2 res[r][n] + gamma[n] * v
+hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int nsplit, const float* bias, const float* gamma,
+                              const float* res, float* y, int R, int N, int K, int epi, hipStream_t s);
+hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
+                                int nsplit, hipStream_t s);
+
 }  // namespace vtq

@@ -101,6 +101,18 @@ class ModelSpec:
     def flops_per_pair(self, num_patches: int) -> float:
         return 2.0 * self.flops_per_image(num_patches) + self.flops_head()
 
+    def flops_per_pair_executed(self, num_patches: int, cls_prune: bool = True) -> float:
+        """Dense flops the engine actually executes per pair.  With the CLS-only last layer (only token 0 is consumed,
+        vtamiq.py:107-108) the last layer keeps the K/V projections for every row and runs Q, attention, out-proj and the
+        MLP for one row per image."""
+        if not cls_prune:
+            return self.flops_per_pair(num_patches)
+        H, M = self.hidden_size, self.mlp_dim
+        S = self.seq_len(num_patches)
+        full_last = 8.0 * S * H * H + 4.0 * S * H * M + 4.0 * S * S * H
+        pruned_last = 4.0 * S * H * H + (4.0 * H * H + 4.0 * H * M + 4.0 * S * H)
+        return self.flops_per_pair(num_patches) - 2.0 * (full_last - pruned_last)
+
     # ---- state_dict layout (reference key names; SURVEY.md section 8b) -----------------------
     def state_layout(self) -> List[Tuple[str, Tuple[int, ...], str]]:
         """[(key, shape, kind)] in the reference's registration order.
