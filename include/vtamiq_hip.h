@@ -126,6 +126,11 @@ int  vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, 
 int  vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane,
                      int32_t nseq, int32_t S, int32_t S_pad, int32_t H, int32_t nsplit, void* stream);
 
+/* fp32 small-batch linear of the DiffNet head: y[b][n] = post(W[n] . pre(x[b]) + bias[n]) (+ res[b][n]); pre/post = PReLU
+ * with the given one-element slope tensors (NULL = identity).  Conv1d(k=1) on (B,C,1) (channel_attention.py:45, 58-61). */
+int  vtq_k_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope, const float* post_slope,
+                        const float* res, float* y, int32_t B, int32_t N, int32_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,26 @@ def test_attention(nsplit, nseq, S, H):
     tol = 1.5e-2 if nsplit == 1 else 2e-4
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
+
+
+@pytest.mark.parametrize("B,N,K", [(2, 768, 768), (32, 768, 768), (37, 192, 768), (64, 1, 192), (5, 768, 96), (3, 1024, 1024)])
+@pytest.mark.parametrize("mode", ["plain", "pre", "post", "res"])
+def test_small_linear(B, N, K, mode):
+    lib = _lib.load()
+    x, W, bias = _randn(B, K, seed=20), _randn(N, K, seed=21, scale=0.05), _randn(N, seed=22)
+    slope = torch.tensor([0.23], device=DEV)
+    res = _randn(B, N, seed=23)
+    y = torch.zeros(B, N, device=DEV)
+    _lib.check(lib.vtq_k_small_linear(x.data_ptr(), W.data_ptr(), bias.data_ptr(), slope.data_ptr() if mode == "pre" else None,
+                                      slope.data_ptr() if mode == "post" else None, res.data_ptr() if mode == "res" else None,
+                                      y.data_ptr(), B, N, K, stream()))
+    torch.cuda.synchronize()
+    xd = x.double()
+    if mode == "pre":
+        xd = torch.where(xd >= 0, xd, 0.23 * xd)
+    ref = xd @ W.double().t() + bias.double()
+    if mode == "post":
+        ref = torch.where(ref >= 0, ref, float(slope.double()) * ref)
+    if mode == "res":
+        ref = ref + res.double()
+    assert (y.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())

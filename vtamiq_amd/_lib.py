@@ -44,6 +44,7 @@ SIGNATURES = {
                              C.c_void_p]),
     "vtq_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "vtq_k_small_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
 }

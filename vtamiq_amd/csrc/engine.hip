@@ -85,6 +85,9 @@ struct vtq_engine {
     float* hhid = nullptr;
     float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr, *h1cls = nullptr;   // CLS-only last layer
     bool cls_prune = true;
+    int nparts = 2;                      // part-batches run on separate streams (VTQ_PARTS; 1 disables)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
     // profiling
@@ -269,6 +272,96 @@ struct Prof {
     }
 };
 
+
+struct Part { int seq0, nseq; int64_t rows; hipStream_t s; };
+
+// All encoder layers for the sequences [seq0, seq0 + nseq) (rows seq0*S_pad ...), enqueued on pt.s.  `skew_after` > 0:
+// record `skew_ev` after that many kernels of layer 0 (the other half-batch is released there).
+int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, int skew_after, hipEvent_t skew_ev) {
+    const vtq_config& c = e->cfg;
+    const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit, L = c.num_layers;
+    hipStream_t s = pt.s;
+    const int M = (int)pt.rows;
+    const int64_t row0 = (int64_t)pt.seq0 * g.S_pad;
+    const int64_t Wmax = (3 * H > Md ? 3 * H : Md);
+    float* x = e->x + row0 * H;
+    char* lnb = (char*)e->lnbuf + row0 * H * 2;
+    char* big = (char*)e->big + row0 * Wmax * 2;             // each part owns a contiguous chunk: QKV (ld 3H) and MLP hidden (ld M) alias inside it only
+    float *xcls = e->xcls + (int64_t)pt.seq0 * H, *lncls = e->lncls + (int64_t)pt.seq0 * H, *qcls = e->qcls + (int64_t)pt.seq0 * H,
+          *acls = e->acls + (int64_t)pt.seq0 * H, *h1cls = e->h1cls + (int64_t)pt.seq0 * Md;
+    const int64_t trace_stride = (int64_t)g.nseq * T * H;
+    int nk = 0;
+    auto tick = [&]() -> int {
+        if (skew_after > 0 && ++nk == skew_after) HIP_TRY(hipEventRecord(skew_ev, s));
+        return 0;
+    };
+    for (int i = 0; i < L; ++i) {
+        const Layer& Ly = e->layers[i];
+        if (prune && i == L - 1) {
+            // ---- last layer: K/V for every row, everything else for the 2B CLS rows only (cls_tail.hip) ------------
+            const int R = pt.nseq;
+            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, ns, s)); }
+            {
+                Prof p(e, s, VTQ_K_QKV);
+                GemmArgs a{};
+                a.A = lnb; a.a_plane = e->ln_plane; a.lda = H;
+                a.W = (const char*)Ly.wqkv + (size_t)H * H * 2; a.w_plane = Ly.pqkv;
+                a.M = M; a.N = 2 * H; a.K = H; a.bias = Ly.bqkv + H;
+                a.out = big + (size_t)H * 2; a.o_plane = e->big_plane; a.ldo = 3 * H;
+                HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+            }
+            {
+                Prof p(e, s, VTQ_K_ATTN);
+                HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, s));
+                HIP_TRY(launch_rows_linear(lncls, Ly.wqkv, Ly.pqkv, ns, Ly.bqkv, nullptr, nullptr, qcls, R, H, H, 0, s));
+                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, ns, s));
+            }
+            {
+                Prof p(e, s, VTQ_K_OUTPROJ);
+                HIP_TRY(launch_rows_linear(acls, Ly.wo, Ly.po, ns, Ly.bo, Ly.g1, xcls, xcls, R, H, H, 2, s));
+            }
+            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s)); }
+            { Prof p(e, s, VTQ_K_FC1); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
+            { Prof p(e, s, VTQ_K_FC2); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
+            break;
+        }
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, ns, s)); }
+        {
+            Prof p(e, s, VTQ_K_QKV);
+            GemmArgs a{};
+            a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
+            a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = big; a.o_plane = e->big_plane; a.ldo = 3 * H;
+            HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+        }
+        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, pt.nseq, g.S, g.S_pad, H, ns, s)); }
+        if (i == 0 && tick()) return 1;
+        {
+            Prof p(e, s, VTQ_K_OUTPROJ);
+            GemmArgs a{};
+            a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
+            a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = x;
+            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+        }
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, ns, s)); }
+        {
+            Prof p(e, s, VTQ_K_FC1);
+            GemmArgs a{};
+            a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
+            a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = big; a.o_plane = e->big_plane; a.ldo = Md;
+            HIP_TRY(launch_gemm(a, ns, EPI_BIAS_GELU, s));
+        }
+        {
+            Prof p(e, s, VTQ_K_FC2);
+            GemmArgs a{};
+            a.A = big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
+            a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = x;
+            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+        }
+        if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride + (int64_t)pt.seq0 * T * H, pt.nseq, g.S_pad, T, H, s));
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -296,6 +389,14 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
     { const char* np = getenv("VTQ_NO_CLS_PRUNE"); e->cls_prune = !(np && np[0] == '1'); }
+    { const char* ps = getenv("VTQ_PARTS"); if (ps) e->nparts = atoi(ps); if (e->nparts != 1 && e->nparts != 2 && e->nparts != 4) e->nparts = 2; }
+    if (e->nparts > 1) {
+        bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < e->nparts - 1; ++i)
+            ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { vtq_destroy(e); return fail("vtq_create: stream/event creation failed"); }
+    }
     if (build(e)) { vtq_destroy(e); return 1; }
     *out = e;
     return 0;
@@ -308,6 +409,11 @@ void vtq_destroy(vtq_handle e) {
     for (void* p : e->ws_allocs) (void)hipFree(p);
     for (auto& ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 3; ++i) {
+        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+        if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+    }
     delete e;
 }
 
@@ -377,7 +483,7 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
     if (reserve(e, B, N)) return 1;
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(e, B, N);
-    const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit;
+    const int H = e->H, T = e->T, ns = e->nsplit;
     const int L = c.num_layers;
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
@@ -400,74 +506,31 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
         HIP_TRY(launch_gemm(a, ns, EPI_EMBED, s));
     }
-    const int64_t trace_stride = (int64_t)g.nseq * T * H;
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.S_pad, T, H, s));
 
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
-    const int M = (int)g.M_pad;
     const bool prune = e->cls_prune && !e->trace;      // the trace tap needs every token row of the last layer
-    for (int i = 0; i < L; ++i) {
-        const Layer& Ly = e->layers[i];
-        if (prune && i == L - 1) {
-            // ---- last layer: K/V for every row, everything else for the 2B CLS rows only (cls_tail.hip) ------------
-            const int R = g.nseq;
-            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln1w, Ly.ln1b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
-            {
-                Prof p(e, s, VTQ_K_QKV);
-                GemmArgs a{};
-                a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H;
-                a.W = (const char*)Ly.wqkv + (size_t)H * H * 2; a.w_plane = Ly.pqkv;
-                a.M = M; a.N = 2 * H; a.K = H; a.bias = Ly.bqkv + H;
-                a.out = (char*)e->big + (size_t)H * 2; a.o_plane = e->big_plane; a.ldo = 3 * H;
-                HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+    // Part-batches on separate streams: the dispatcher then always has ready workgroups of a DIFFERENT kernel to fill
+    // partially occupied rounds (N = 768 GEMMs are 1.5 rounds at B = 32), and one part's store bursts / LayerNorm overlap
+    // another part's MFMA loops.  Parts are contiguous sequence ranges (ref images first), all kernels are row-independent.
+    int nparts = e->nparts;
+    while (nparts > 1 && (g.nseq % nparts || ((int64_t)(g.nseq / nparts) * g.S_pad) % 256)) nparts >>= 1;
+    if (nparts > 1 && L > 1) {
+        const int per = g.nseq / nparts;
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        for (int pi = 0; pi < nparts; ++pi) {
+            hipStream_t ps = pi == 0 ? s : e->side[pi - 1];
+            if (pi) HIP_TRY(hipStreamWaitEvent(ps, e->ev_fork, 0));
+            Part pt{pi * per, per, (int64_t)per * g.S_pad, ps};
+            if (run_encoder(e, g, pt, prune, 0, nullptr)) return 1;
+            if (pi) {
+                HIP_TRY(hipEventRecord(e->ev_join[pi - 1], ps));
+                HIP_TRY(hipStreamWaitEvent(s, e->ev_join[pi - 1], 0));
             }
-            {
-                Prof p(e, s, VTQ_K_ATTN);
-                HIP_TRY(launch_rows_ln(e->x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, e->lncls, e->xcls, R, H, s));
-                HIP_TRY(launch_rows_linear(e->lncls, Ly.wqkv, Ly.pqkv, ns, Ly.bqkv, nullptr, nullptr, e->qcls, R, H, H, 0, s));
-                HIP_TRY(launch_cls_attention(e->qcls, e->big, e->big_plane, e->acls, R, g.S, g.S_pad, H, ns, s));
-            }
-            {
-                Prof p(e, s, VTQ_K_OUTPROJ);
-                HIP_TRY(launch_rows_linear(e->acls, Ly.wo, Ly.po, ns, Ly.bo, Ly.g1, e->xcls, e->xcls, R, H, H, 2, s));
-            }
-            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_rows_ln(e->xcls, H, Ly.ln2w, Ly.ln2b, e->lncls, nullptr, R, H, s)); }
-            { Prof p(e, s, VTQ_K_FC1); HIP_TRY(launch_rows_linear(e->lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, e->h1cls, R, Md, H, 1, s)); }
-            { Prof p(e, s, VTQ_K_FC2); HIP_TRY(launch_rows_linear(e->h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, e->xcls, e->xcls, R, H, Md, 2, s)); }
-            break;
         }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln1w, Ly.ln1b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
-        {
-            Prof p(e, s, VTQ_K_QKV);
-            GemmArgs a{};
-            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
-            a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = e->big; a.o_plane = e->big_plane; a.ldo = 3 * H;
-            HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
-        }
-        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(e->big, e->big_plane, e->lnbuf, e->ln_plane, g.nseq, g.S, g.S_pad, H, ns, s)); }
-        {
-            Prof p(e, s, VTQ_K_OUTPROJ);
-            GemmArgs a{};
-            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
-            a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = e->x;
-            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
-        }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(e->x, Ly.ln2w, Ly.ln2b, e->lnbuf, e->ln_plane, M, H, ns, s)); }
-        {
-            Prof p(e, s, VTQ_K_FC1);
-            GemmArgs a{};
-            a.A = e->lnbuf; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
-            a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = e->big; a.o_plane = e->big_plane; a.ldo = Md;
-            HIP_TRY(launch_gemm(a, ns, EPI_BIAS_GELU, s));
-        }
-        {
-            Prof p(e, s, VTQ_K_FC2);
-            GemmArgs a{};
-            a.A = e->big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
-            a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = e->x;
-            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
-        }
-        if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace + (i + 1) * trace_stride, g.nseq, g.S_pad, T, H, s));
+    } else {
+        Part pa{0, g.nseq, g.M_pad, s};
+        if (run_encoder(e, g, pa, prune, 0, nullptr)) return 1;
     }
 
     // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------
@@ -527,6 +590,12 @@ int vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, i
 int vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int32_t nseq, int32_t S, int32_t S_pad,
                     int32_t H, int32_t nsplit, void* stream) {
     HIP_TRY(launch_attention(qkv, plane, out, o_plane, nseq, S, S_pad, H, nsplit, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope, const float* post_slope,
+                       const float* res, float* y, int32_t B, int32_t N, int32_t K, void* stream) {
+    HIP_TRY(launch_small_linear(x, W, bias, pre_slope, post_slope, res, y, B, N, K, (hipStream_t)stream));
     return 0;
 }
 
