@@ -14,21 +14,35 @@
 //   * K tile chunks are XOR-swizzled ((row>>1)&7) for conflict-free ds_read_b128; V tile 64-byte halves are swapped on
 //     rows with bit 1 set so the four rows of a transposed read hit disjoint banks;
 //   * NSPLIT == 3: Q,K,V,P are hi/lo bf16 pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
+#include <cstdlib>
+
+#ifndef VTQ_ATT_ABL
+#define VTQ_ATT_ABL 0      // diagnostic ablations (build with -DVTQ_ATT_ABL=n): 1 no exp, 2 no hi/lo correction MFMAs, 4 no P split
+#endif
+
 #include "dev_common.h"
 #include "kernels.h"
 
 namespace vtq {
 namespace {
 
+template <int N> __device__ __forceinline__ void wait_dma_attn() {
+    static_assert(N == 4 || N == 8 || N == 16, "vmcnt immediate");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
-template <int NSPLIT>
+template <int NSPLIT, int NSTAGE, int KT>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, int64_t plane, bf16* __restrict__ out,
                                                         int64_t o_plane, int S, int S_pad, int H) {
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
-    constexpr int TB = 64 * 128;             // one 64-key x 64-dim bf16 tile
+    constexpr int KB = KT / 32;              // 32-key blocks per K/V tile (KT = 64 | 32 keys)
+    constexpr int TB = KT * 128;             // one KT-key x 64-dim bf16 tile
     constexpr int STAGE = TB * NPL * 2;      // K planes then V planes
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -60,9 +74,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             qf[pl][t] = *(const bf16x8*)(qkv + pl * plane + (row0 + q_row) * ld + head * 64 + 16 * t + 8 * hh);
 
     // ---- DMA source offsets (elements) of this thread for the two rounds of a 64-row tile --------------------
-    uint32_t k_off[2], v_off[2];
+    uint32_t k_off[KB], v_off[KB];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < KB; ++r) {
         const int slot = r * 256 + tid;
         const int row = slot >> 3, s = slot & 7;
         k_off[r] = (uint32_t)(row * ld + H + head * 64 + ((s ^ ((row >> 1) & 7)) << 3));
@@ -70,11 +84,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     }
     auto stage = [&](int t, int buf) {
         char* sb = smem + buf * STAGE + wave * 1024;
-        const bf16* base = qkv + (row0 + (int64_t)t * 64) * ld;
+        const bf16* base = qkv + (row0 + (int64_t)t * KT) * ld;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < KB; ++r) {
                 glds16(base + pl * plane + k_off[r], sb + pl * TB + r * 4096);
                 glds16(base + pl * plane + v_off[r], sb + (NPL + pl) * TB + r * 4096);
             }
@@ -96,27 +110,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     float m_run = -1e30f, l_run = 0.f;
     const float sc = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
 
-    const int nt = S_pad / 64;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NSTAGE-deep K/V ring: tile t+NSTAGE-1 is in flight while tile t is consumed (counted vmcnt, one barrier per tile)
+    constexpr int DMA_PER_TILE = 2 * KB * NPL;
+    const int nt = S_pad / KT;
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < nt) stage(t, t);
+    if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nt >= NSTAGE - 1) wait_dma_attn<DMA_PER_TILE*(NSTAGE - 2)>();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        int nxt = cur + NSTAGE - 1; if (nxt >= NSTAGE) nxt -= NSTAGE;
+        if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, nxt);
         const char* sk = smem + cur * STAGE;
         const char* sv = sk + NPL * TB;
 
         // ---- S^T[key][q] for the 64 keys of this tile ---------------------------------------------------------
-        f32x16 sacc[2];
+        f32x16 sacc[KB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KB; ++kb) {
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int off = kb * 32 * 128 + k_rd + (((2 * tt + hh) ^ k_sw) << 4);
                 const bf16x8 kf = *(const bf16x8*)(sk + off);
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], tt == 0 ? zero16 : sacc[kb], 0, 0, 0);
-                if constexpr (NSPLIT == 3) {
+                if constexpr (NSPLIT == 3 && !(VTQ_ATT_ABL & 2)) {
                     const bf16x8 kl = *(const bf16x8*)(sk + TB + off);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][tt], sacc[kb], 0, 0, 0);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][tt], sacc[kb], 0, 0, 0);
@@ -125,27 +146,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         }
 
         // ---- online softmax (base-2 domain; scale folded into one FMA per score) -----------------------------------
-        if ((t == nt - 1) && (S < S_pad)) {     // wave-uniform: only the last tile holds padded keys
+        if ((t + 1) * KT > S) {                 // wave-uniform: only the last tile(s) hold padded keys
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     if (key >= S) sacc[kb][r] = -INFINITY;
                 }
         }
-        float mx = fmaxf(sacc[0][0], sacc[1][0]);
+        float mx = sacc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);       // v_max3_f32
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                                              // raw (unscaled) running max
         const float nm = -m_new * sc;
         float rs = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if (VTQ_ATT_ABL & 1)
+                const float pv = fmaf(sacc[kb][r], sc, nm);
+#else
                 const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
+#endif
                 sacc[kb][r] = pv;
                 rs += pv;
             }
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q] -------------------------------------------------------------
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 ph, pl_;
@@ -170,7 +197,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 for (int j = 0; j < 8; ++j) {
                     const float pv = sacc[kb][8 * s2 + j];
                     if constexpr (NSPLIT == 1) ph[j] = (bf16)pv;
+#if (VTQ_ATT_ABL & 4)
+                    else { ph[j] = (bf16)pv; pl_[j] = (bf16)pv; }
+#else
                     else { bf16 a, b; split2(pv, a, b); ph[j] = a; pl_[j] = b; }
+#endif
                 }
                 const int vrow = kb * 32 + 16 * s2 + v_row;
 #pragma unroll
@@ -181,7 +212,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     const bf16x4 v1 = lds_tr16(a0 + 8 * 128);
                     const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, o_acc[d], 0, 0, 0);
-                    if constexpr (NSPLIT == 3) {
+                    if constexpr (NSPLIT == 3 && !(VTQ_ATT_ABL & 2)) {
                         const bf16x4 w0 = lds_tr16(a0 + TB);
                         const bf16x4 w1 = lds_tr16(a0 + TB + 8 * 128);
                         const bf16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
@@ -191,9 +222,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 }
             }
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile t+1 must have landed; younger tiles (t+2 .. t+NSTAGE-1) may stay in flight
+        {
+            const int younger = nt - 2 - t < NSTAGE - 2 ? nt - 2 - t : NSTAGE - 2;
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger >= 2) wait_dma_attn<DMA_PER_TILE * 2>();
+            else if (younger == 1) wait_dma_attn<DMA_PER_TILE>();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        cur ^= 1;
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
     // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
@@ -225,25 +263,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
 }  // namespace
 
+template <int NSPLIT, int NSTAGE, int KT>
+hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s) {
+    constexpr int LDS = NSTAGE * 2 * KT * 128 * (NSPLIT == 1 ? 1 : 2);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<NSPLIT, NSTAGE, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
+    hipLaunchKernelGGL((attention_kernel<NSPLIT, NSTAGE, KT>), grid, blk, LDS, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S, S_pad, H);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s) {
     if (H % 64 || S_pad % 64 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-    const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
+    const char* st = getenv("VTQ_ATTN_VARIANT");      // experiments: "s<stages>k<keys>" e.g. s2k32
+    const int v = st ? atoi(st) : 0;
     if (nsplit == 1) {
-        hipLaunchKernelGGL(attention_kernel<1>, grid, blk, 2 * 64 * 128 * 2, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S,
-                           S_pad, H);
-    } else {
-        static bool configured = false;
-        if (!configured) {
-            hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               2 * 64 * 128 * 4);
-            if (e != hipSuccess) return e;
-            configured = true;
-        }
-        hipLaunchKernelGGL(attention_kernel<3>, grid, blk, 2 * 64 * 128 * 4, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S,
-                           S_pad, H);
+        if (v == 232) return launch_attention_t<1, 2, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+        if (v == 364) return launch_attention_t<1, 3, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+        return launch_attention_t<1, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
     }
-    return hipGetLastError();
+    if (v == 232) return launch_attention_t<3, 2, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    if (v == 332) return launch_attention_t<3, 3, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    return launch_attention_t<3, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
 }
 
 }  // namespace vtq
