@@ -54,7 +54,7 @@ struct Layer {
     int64_t pqkv, po, p1, p2;                  // plane strides
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b, *g1, *g2;
 };
-struct Rcab { float *slope, *w, *b, *wd, *bd, *wu, *bu; };
+struct Rcab { float *slope, *w, *b, *wd, *bd, *wu, *bu, *wcat, *bcat; };   // wcat/bcat: [Wc ; Wd Wc], folded at load time
 struct Rg { std::vector<Rcab> rcabs; float *w, *b; };
 
 }  // namespace
@@ -179,6 +179,7 @@ int build(vtq_engine* e) {
                     add_f32(e, p + "4.conv_du.1.bias", &r.bd, hid) || add_f32(e, p + "4.conv_du.4.weight", &r.wu, H * hid) ||
                     add_f32(e, p + "4.conv_du.4.bias", &r.bu, H))
                     return 1;
+                if (dev_alloc(e, (void**)&r.wcat, (size_t)(H + hid) * H * 4) || dev_alloc(e, (void**)&r.bcat, (size_t)(H + hid) * 4)) return 1;
             }
             const std::string p = "quality_decoder." + std::to_string(g) + ".body." + std::to_string(c.num_rcabs) + ".";
             if (add_f32(e, p + "weight", &R.w, H * H) || add_f32(e, p + "bias", &R.b, H)) return 1;
@@ -431,6 +432,9 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
     }
+    for (auto& R : e->rgs)
+        for (auto& r : R.rcabs)
+            HIP_TRY(launch_fold_ca(r.w, r.b, r.wd, r.bd, r.wcat, r.bcat, e->H, e->cfg.ca_hidden, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
@@ -547,8 +551,7 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
                 const float* y = xr;
                 float* yo = y0;
                 for (auto& r : R.rcabs) {
-                    HIP_TRY(launch_small_linear(y, r.w, r.b, r.slope, nullptr, nullptr, cb, B, H, H, s));
-                    HIP_TRY(launch_ca_residual(cb, y, r.wd, r.bd, r.wu, r.bu, e->hhid, yo, B, H, c.ca_hidden, s));
+                    HIP_TRY(launch_rcab(y, r.slope, r.wcat, r.bcat, r.wu, r.bu, cb, e->hhid, yo, B, H, c.ca_hidden, s));
                     y = yo;
                     yo = (yo == y0) ? y1 : y0;
                 }

@@ -57,9 +57,11 @@ hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_
 hipError_t launch_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope,
                                const float* post_slope, const float* res, float* y, int B, int N, int K, hipStream_t s);
 
-// channel attention + RCAB residual: out[b] = r[b] + c[b] * sigmoid(Wu relu(Wd c[b] + bd) + bu)
-hipError_t launch_ca_residual(const float* c, const float* r, const float* Wd, const float* bd, const float* Wu,
-                              const float* bu, float* t, float* out, int B, int H, int hid, hipStream_t s);
+// RCAB in two launches with folded weights [Wc ; Wd Wc] (launch_fold_ca, once per weight load): c, t scratch; out = r + c * sigmoid(Wu t + bu)
+hipError_t launch_rcab(const float* r, const float* slope, const float* Wcat, const float* bcat, const float* Wu, const float* bu,
+                       float* c, float* t, float* out, int B, int H, int hid, hipStream_t s);
+hipError_t launch_fold_ca(const float* Wc, const float* bc, const float* Wd, const float* bd, float* Wcat, float* bcat, int H, int hid,
+                          hipStream_t s);
 
 // ---- CLS-only tail of the last encoder layer (cls_tail.hip) -----------------------------------------------------------
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
