@@ -29,8 +29,9 @@ def synth_inputs_on_device(torch, spec, B, N, device, seed):
 
 
 def fc1_traffic(precision, B):
-    """HBM bytes per fc1 launch from the committed PMC passes (profiles/r01_gemm_fc1_traffic.json: FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, collected at B=32 in separate rocprofv3 --pmc runs); scaled linearly with the batch."""
+    """HBM bytes of ONE full-batch fc1 GEMM (M = 2*B*S_pad rows) from the committed PMC passes
+    (profiles/r01_gemm_fc1_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected at B=32 in separate
+    rocprofv3 --pmc runs); scaled linearly with the batch."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_fc1_traffic.json")))
         return d[precision]["bytes_per_launch"] * (B / 32.0)
@@ -177,12 +178,20 @@ def main():
     }
     if prof and prof[1] > 0:
         ms_sum, launches = prof
-        flops_launch = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim      # algorithmic, unpadded rows
+        # fc1 GEMM launches per step: (layers that run the full MLP) x (part-batches); all launches have the same shape
+        pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
+        full_layers = spec.num_layers - (1 if pruned else 0)
+        per_step = launches / a.steps
+        flops_launch = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim * full_layers / per_step    # algorithmic, unpadded rows
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": f"gemm_bf16_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1)",
+        traffic = fc1_traffic(a.precision, B)
+        out["roofline"] = {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1 of every full layer)",
                            "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                           "traffic": fc1_traffic(a.precision, B), "avg_launch_ms": ms_sum / launches, "launches": int(launches),
-                           "flops_per_launch": flops_launch}
+                           "traffic": traffic * full_layers / per_step if traffic else None,
+                           "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
+                           "flops_per_launch": flops_launch,
+                           "note": "HIP events on the launch stream inside the timed region; with 2 part-batches on 2 streams a launch "
+                                   "covers half the rows and shares the chip with the other stream's kernels"}
     if rank == 0 and not a.no_second_mode:
         other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         del model

@@ -212,6 +212,38 @@ def run_plumbing():
     print("plumbing_c1:", q.numpy(), q_p.numpy())
 
 
+def run_npz():
+    """JAX .npz ingestion.  A tiny synthetic checkpoint (grid 3x3 -> resized to the model's 4x4) is loaded by the
+    reference's VisionTransformer.load_from; inputs and the resulting state_dict are the fixture."""
+    from modules.VisionTransformer import transformer as T
+    rs = np.random.RandomState(5)
+    H, M, L, P = 32, 64, 2, 16
+    cfg = dict(vit_weights_path="", img_dim=64, patch_size=P, hidden_size=H, mlp_dim=M, num_heads=4, num_layers=3)
+    w = {"embedding/kernel": rs.randn(P, P, 3, H), "embedding/bias": rs.randn(H), "cls": rs.randn(1, 1, H),
+         "Transformer/posembed_input/pos_embedding": rs.randn(1, 3 * 3 + 1, H),
+         "Transformer/encoder_norm/scale": rs.randn(H), "Transformer/encoder_norm/bias": rs.randn(H)}
+    for i in range(3):
+        r = f"Transformer/encoderblock_{i}"
+        for nm in ("query", "key", "value"):
+            w[f"{r}/MultiHeadDotProductAttention_1/{nm}/kernel"] = rs.randn(H, 4, H // 4)
+            w[f"{r}/MultiHeadDotProductAttention_1/{nm}/bias"] = rs.randn(4, H // 4)
+        w[f"{r}/MultiHeadDotProductAttention_1/out/kernel"] = rs.randn(4, H // 4, H)
+        w[f"{r}/MultiHeadDotProductAttention_1/out/bias"] = rs.randn(H)
+        w[f"{r}/MlpBlock_3/Dense_0/kernel"] = rs.randn(H, M); w[f"{r}/MlpBlock_3/Dense_0/bias"] = rs.randn(M)
+        w[f"{r}/MlpBlock_3/Dense_1/kernel"] = rs.randn(M, H); w[f"{r}/MlpBlock_3/Dense_1/bias"] = rs.randn(H)
+        for ln in ("LayerNorm_0", "LayerNorm_2"):
+            w[f"{r}/{ln}/scale"] = rs.randn(H); w[f"{r}/{ln}/bias"] = rs.randn(H)
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    vit = T.VisionTransformer(cfg, use_classifier=False, num_keep_layers=L, num_extra_tokens=2, pretrained=False)
+    vit.load_from(w, True, True)
+    out = {"in/" + k: v for k, v in w.items()}
+    for k, v in vit.state_dict().items():
+        out["sd/transformer." + k] = v.numpy()
+    out["meta"] = np.array([H, L, 4 * 4 + 1])
+    np.savez(os.path.join(HERE, "npz_ingest_tiny.npz"), **out)
+    print("npz_ingest_tiny:", len(out), "arrays")
+
+
 def main():
     sys.path.insert(0, REF)
     _install_stubs()
@@ -233,6 +265,7 @@ def main():
     run_case("nocalib_b2_n30", dict(vit_config=dict(variant=B16, num_keep_layers=1), calibrate=False, diff_scale=False),
              B=2, N=30, wseed=7, iseed=17)
     run_ops()
+    run_npz()
     run_plumbing()
 
 

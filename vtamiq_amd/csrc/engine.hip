@@ -312,18 +312,18 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, in
                 HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
             }
             {
-                Prof p(e, s, VTQ_K_ATTN);
+                Prof p(e, s, VTQ_K_HEAD);
                 HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, s));
                 HIP_TRY(launch_rows_linear(lncls, Ly.wqkv, Ly.pqkv, ns, Ly.bqkv, nullptr, nullptr, qcls, R, H, H, 0, s));
                 HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, ns, s));
             }
             {
-                Prof p(e, s, VTQ_K_OUTPROJ);
+                Prof p(e, s, VTQ_K_HEAD);
                 HIP_TRY(launch_rows_linear(acls, Ly.wo, Ly.po, ns, Ly.bo, Ly.g1, xcls, xcls, R, H, H, 2, s));
             }
-            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s)); }
-            { Prof p(e, s, VTQ_K_FC1); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
-            { Prof p(e, s, VTQ_K_FC2); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
+            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s)); }
+            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
+            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
             break;
         }
         { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, ns, s)); }
