@@ -83,6 +83,13 @@ int  vtq_forward(vtq_handle h,
                  const float* scales_ref, const float* scales_dist,
                  int32_t B, int32_t N, float* q_out, void* stream);
 
+/* Pairwise items (train.predict, train.py:281-301: two model calls sharing the reference image): patches/pos/scales are HOST
+ * arrays of 3 DEVICE pointers {ref, dist1, dist2}, each as in vtq_forward (scales may be NULL); the reference image is
+ * encoded ONCE (3B sequences instead of 4B).  q_out[2B]: q_out[b] = score(ref_b, dist1_b), q_out[B + b] = score(ref_b, dist2_b);
+ * bit-identical to two vtq_forward calls. */
+int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float* const* pos, const float* const* scales,
+                          int32_t B, int32_t N, float* q_out, void* stream);
+
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors
  * vit_config["return_layers"] (transformer.py:369-372, 632-636). */

@@ -144,6 +144,43 @@ def test_cls_pruned_last_layer_matches_full_layer(name, monkeypatch):
     assert gate(q_pruned, q_full, 3e-4), rel_err(q_pruned, q_full)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_pairwise_triplets(precision):
+    """(ref, dist1, dist2) items.  The fused entry point encodes ref once and must reproduce the two model calls of
+    train.py:286-287 bit for bit; predict() then applies the PreferenceModule / sigmoid exactly like train.py:296-301."""
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=3, num_scales=3))
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+    sd = synth.make_state_dict(m.spec, 31)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    B, N = 4, 60
+    patches, pos, scales = synth.make_inputs(m.spec, B, N, 32, aligned=False)
+    rs = np.random.RandomState(3)
+    p3 = np.concatenate([patches, np.clip(patches[:, :1] + 0.2 * rs.randn(*patches[:, :1].shape), -1, 1).astype(np.float32)], axis=1)
+    pos3 = np.concatenate([pos, pos[:, 1:2]], axis=1)
+    sc3 = np.concatenate([scales, scales[:, 1:2]], axis=1)
+    q_true = torch.zeros(B, dtype=torch.float64)
+    batch = (q_true, torch.from_numpy(p3), torch.from_numpy(pos3), torch.from_numpy(sc3))
+    from vtamiq_amd import PreferenceModule
+    pref = PreferenceModule(1.7).to(DEV)
+    with torch.no_grad():
+        data = get_data_tuple(batch, torch.device(DEV))
+        q, q_p, feats = predict(m, pref, data, True, False, True)
+        pr, pd1, pd2 = (data[1][:, i].clone() for i in range(3))
+        qr, qd1, qd2 = (data[2][:, i].clone() for i in range(3))
+        sr, sd1, sd2 = (data[3][:, i].clone() for i in range(3))
+        q1 = m((pr, pd1), (qr, qd1), (sr, sd1))[0]
+        q2 = m((pr, pd2), (qr, qd2), (sr, sd2))[0]
+        f1, f2 = m.forward_pairwise((pr, pd1, pd2), (qr, qd1, qd2), (sr, sd1, sd2))
+    assert torch.equal(f1, q1) and torch.equal(f2, q2)
+    assert torch.equal(q_p, torch.sigmoid(1.7 * (q2 - q1)))
+    # and against the oracle's two forward calls
+    c = lambda t: t.cpu()
+    o1 = O.vtamiq_forward(O.to_torch(sd), m.spec, (c(pr), c(pd1)), (c(qr), c(qd1)), (c(sr), c(sd1)))[0].numpy()
+    o2 = O.vtamiq_forward(O.to_torch(sd), m.spec, (c(pr), c(pd2)), (c(qr), c(qd2)), (c(sr), c(sd2)))[0].numpy()
+    assert gate(np.concatenate([f1.cpu().numpy(), f2.cpu().numpy()]), np.concatenate([o1, o2]), TOL[precision])
+
+
 def test_rejects_what_the_reference_rejects():
     model, _ = _c2_model("bf16")
     p = torch.zeros(1, 8, 3, 16, 16, device=DEV)

@@ -98,3 +98,26 @@ def test_flop_model_matches_baseline_md():
     assert abs(d.flops_per_pair(500) / 9.7221e10 - 1) < 1e-3
     l = make_spec(dict(variant="ViT-L16", num_scales=3))
     assert abs(l.flops_per_pair(1024) / 1.4480e12 - 1) < 1e-3
+
+
+def test_predict_pairwise_branch_matches_reference_semantics():
+    """train.py:281-301 on CPU with a stand-in model: two calls sharing `ref`, PreferenceModule = sigmoid(p (q2 - q1)),
+    and the fallback sigmoid(q1 - q2) (opposite sign convention, reproduced not fixed)."""
+    from vtamiq_amd.predict import predict, PreferenceModule
+    B, N = 3, 5
+    g = torch.Generator().manual_seed(0)
+    patches = torch.randn(B, 3, N, 3, 16, 16, generator=g)
+    pos = torch.rand(B, 3, N, 2, generator=g)
+    scales = torch.zeros(B, 3, N)
+    calls = []
+
+    def model(p, ps, sc):
+        calls.append((p, ps, sc))
+        return (p[0].mean(dim=(1, 2, 3, 4)) - p[1].mean(dim=(1, 2, 3, 4)), None)
+    q, q_p, feats = predict(model, PreferenceModule([2.0]), (torch.zeros(B), patches, pos, scales), True, False, False)
+    assert len(calls) == 2 and calls[0][2] == (None, None) and torch.equal(calls[0][0][0], calls[1][0][0])
+    q1 = patches[:, 0].mean(dim=(1, 2, 3, 4)) - patches[:, 1].mean(dim=(1, 2, 3, 4))
+    q2 = patches[:, 0].mean(dim=(1, 2, 3, 4)) - patches[:, 2].mean(dim=(1, 2, 3, 4))
+    assert torch.allclose(q_p, torch.sigmoid(2.0 * (q2 - q1)))
+    _, q_p2, _ = predict(model, None, (torch.zeros(B), patches, pos, scales), True, False, False)
+    assert torch.allclose(q_p2, torch.sigmoid(q1 - q2))

@@ -35,6 +35,8 @@ SIGNATURES = {
     "vtq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "vtq_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "vtq_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_forward_pairwise": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

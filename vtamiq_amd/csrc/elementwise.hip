@@ -32,46 +32,50 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     }
 }
 
-// rows [0,BN) from ref, [BN,2BN) from dist, [2BN,rows_pad) zero.  K = 768 floats per row.
+// rows [k*BN, (k+1)*BN) from image k (k < nimg: ref, dist[, dist2]); rows >= nimg*BN zero.  K = 768 floats per row.
+struct ImgPtrs { const float* p[3]; };
+
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void pack_patches_kernel(const float* __restrict__ ref, const float* __restrict__ dist,
-                                                           bf16* __restrict__ dst, int64_t plane, int BN, int K4,
+__global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, bf16* __restrict__ dst, int64_t plane, int BN, int K4,
                                                            int64_t total4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / K4;
         const int c4 = (int)(i - row * K4);
+        const int img = (int)(row / BN);
         float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < BN) v = ((const float4*)ref)[row * K4 + c4];
-        else if (row < 2 * (int64_t)BN) v = ((const float4*)dist)[(row - BN) * K4 + c4];
+        if (img < nimg) {
+            const float* sp = img == 0 ? src.p[0] : (img == 1 ? src.p[1] : src.p[2]);
+            v = ((const float4*)sp)[(row - (int64_t)img * BN) * K4 + c4];
+        }
         store4<NSPLIT>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
     }
 }
 
 // UvPosEmbedding.forward index (transformer.py:417-421): floor(pos*G) -> i0*G + i1 + 1, evaluated in fp32 like torch;
 // ScaleEmbedding.forward index (transformer.py:396-398): clamp(scale, 0, num_scales-1) + 1.
-__global__ void embed_index_kernel(const float* __restrict__ pos_ref, const float* __restrict__ pos_dist,
-                                   const float* __restrict__ sc_ref, const float* __restrict__ sc_dist, int* __restrict__ pidx,
-                                   int* __restrict__ sidx, int* __restrict__ row_map, int B, int N, int rows_pad, int S_pad,
-                                   int T, int grid, int num_scales) {
+__global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __restrict__ pidx, int* __restrict__ sidx,
+                                   int* __restrict__ row_map, int B, int N, int rows_pad, int S_pad, int T, int grid, int num_scales) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows_pad) return;
     const int BN = B * N;
-    if (r >= 2 * BN) { pidx[r] = 0; sidx[r] = 0; row_map[r] = -1; return; }
-    const int side = r >= BN;
-    const int rr = r - side * BN;
-    const float* pp = (side ? pos_dist : pos_ref) + (int64_t)rr * 2;
+    const int img = r / BN;
+    if (img >= nimg) { pidx[r] = 0; sidx[r] = 0; row_map[r] = -1; return; }
+    const int rr = r - img * BN;
+    const float* pb = img == 0 ? pos.p[0] : (img == 1 ? pos.p[1] : pos.p[2]);
+    const float* pp = pb + (int64_t)rr * 2;
     const float g = (float)grid;
     const float f0 = floorf(pp[0] * g), f1 = floorf(pp[1] * g);
     pidx[r] = (int)(f0 * g + f1 + 1.0f);
     int si = 0;
-    if (sc_ref) {
-        float sv = (side ? sc_dist : sc_ref)[rr];
+    if (sc.p[0]) {
+        const float* sb = img == 0 ? sc.p[0] : (img == 1 ? sc.p[1] : sc.p[2]);
+        float sv = sb[rr];
         sv = fminf(fmaxf(sv, 0.0f), (float)(num_scales - 1)) + 1.0f;
         si = (int)sv;
     }
     sidx[r] = si;
     const int b = rr / N, n = rr - b * N;
-    row_map[r] = (side * B + b) * S_pad + T + n;
+    row_map[r] = (img * B + b) * S_pad + T + n;
 }
 
 // Embeddings.forward_tokens (transformer.py:507-524): row 0 = cls + pos_table[0]; rows 1..T-1 = register tokens.
@@ -156,10 +160,10 @@ __global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict_
                                                         float* __restrict__ d, int B, int S_pad) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x;
-    const int pb = blockIdx.x;
+    const int pb = blockIdx.x, j = blockIdx.y;           // j-th distorted image (0 for FR pairs; 0,1 for pairwise triplets)
     float4 yr[V4], yd[V4];
     ln_row<V4>(x + (int64_t)pb * S_pad * H, w, b, lane, yr);
-    ln_row<V4>(x + (int64_t)(B + pb) * S_pad * H, w, b, lane, yd);
+    ln_row<V4>(x + (int64_t)((j + 1) * B + pb) * S_pad * H, w, b, lane, yd);
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
         float4 r = {yr[i].x - yd[i].x, yr[i].y - yd[i].y, yr[i].z - yd[i].z, yr[i].w - yd[i].w};
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict_
             const float4 g4 = ((const float4*)gamma)[i * 64 + lane];
             r.x *= g4.x; r.y *= g4.y; r.z *= g4.z; r.w *= g4.w;
         }
-        ((float4*)(d + (int64_t)pb * H))[i * 64 + lane] = r;
+        ((float4*)(d + (int64_t)(j * B + pb) * H))[i * 64 + lane] = r;
     }
 }
 
@@ -186,24 +190,24 @@ hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t
     return hipGetLastError();
 }
 
-hipError_t launch_pack_patches(const float* ref, const float* dist, void* dst, int64_t plane, int BN, int K, int rows_pad,
-                               int nsplit, hipStream_t s) {
+hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int nsplit,
+                               hipStream_t s) {
     const int K4 = K / 4;
     const int64_t total4 = (int64_t)rows_pad * K4;
+    ImgPtrs ip{{imgs[0], imgs[1], nimg > 2 ? imgs[2] : nullptr}};
     if (nsplit == 1)
-        hipLaunchKernelGGL(pack_patches_kernel<1>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ref, dist, (bf16*)dst, plane,
-                           BN, K4, total4);
+        hipLaunchKernelGGL(pack_patches_kernel<1>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (bf16*)dst, plane, BN, K4, total4);
     else
-        hipLaunchKernelGGL(pack_patches_kernel<3>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ref, dist, (bf16*)dst, plane,
-                           BN, K4, total4);
+        hipLaunchKernelGGL(pack_patches_kernel<3>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (bf16*)dst, plane, BN, K4, total4);
     return hipGetLastError();
 }
 
-hipError_t launch_embed_index(const float* pos_ref, const float* pos_dist, const float* sc_ref, const float* sc_dist, int* pidx,
-                              int* sidx, int* row_map, int B, int N, int rows_pad, int S_pad, int T, int grid, int num_scales,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pos_ref, pos_dist, sc_ref, sc_dist,
-                       pidx, sidx, row_map, B, N, rows_pad, S_pad, T, grid, num_scales);
+hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
+                              int rows_pad, int S_pad, int T, int grid, int num_scales, hipStream_t s) {
+    ImgPtrs pp{{pos[0], pos[1], nimg > 2 ? pos[2] : nullptr}};
+    ImgPtrs sp{{sc ? sc[0] : nullptr, sc ? sc[1] : nullptr, (sc && nimg > 2) ? sc[2] : nullptr}};
+    hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pp, sp, nimg, pidx, sidx, row_map, B, N, rows_pad,
+                       S_pad, T, grid, num_scales);
     return hipGetLastError();
 }
 
@@ -238,10 +242,10 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, void
     return hipGetLastError();
 }
 
-hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B,
+hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
                              int S_pad, int H, hipStream_t s) {
-    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
-    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
+    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
+    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -199,13 +199,14 @@ struct Geometry {
     int64_t M_pad, P_pad, rows_alloc;
 };
 
-Geometry geometry(const vtq_engine* e, int B, int N) {
+// nimg images per item: 2 = (ref, dist) FR pair, 3 = (ref, dist1, dist2) pairwise triplet
+Geometry geometry(const vtq_engine* e, int B, int N, int nimg = 2) {
     Geometry g;
     g.S = N + e->T;
     g.S_pad = (int)round_up(g.S, 64);
-    g.nseq = 2 * B;
+    g.nseq = nimg * B;
     g.M_pad = round_up((int64_t)g.nseq * g.S_pad, 256);
-    g.P_pad = round_up((int64_t)2 * B * N, 256);
+    g.P_pad = round_up((int64_t)nimg * B * N, 256);
     g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention query over-read slack
     return g;
 }
@@ -218,7 +219,7 @@ size_t workspace_bytes(const vtq_engine* e, int B, int N) {
     b += (size_t)g.rows_alloc * H * 2 * e->npl;           // LN / attention output planes
     b += (size_t)g.rows_alloc * Wmax * 2 * e->npl;        // qkv | mlp hidden | packed patches planes
     b += (size_t)g.P_pad * 4 * 3;                         // pos/scale indices, row map
-    b += (size_t)B * H * 4 * 6;                           // head ping-pong buffers
+    b += (size_t)2 * B * H * 4 * 6;                       // head ping-pong buffers (pairwise: 2 scores per item)
     b += (size_t)2 * B * (4 * H + e->Mdim) * 4;           // CLS-only last-layer rows
     return b;
 }
@@ -240,10 +241,10 @@ int reserve(vtq_engine* e, int B, int N) {
         dev_alloc(e, &e->big, (size_t)e->big_plane * 2 * e->npl, true) ||
         dev_alloc(e, (void**)&e->pidx, (size_t)g.P_pad * 4, true) || dev_alloc(e, (void**)&e->sidx, (size_t)g.P_pad * 4, true) ||
         dev_alloc(e, (void**)&e->row_map, (size_t)g.P_pad * 4, true) ||
-        dev_alloc(e, (void**)&e->hhid, (size_t)nB * H * 4, true))
+        dev_alloc(e, (void**)&e->hhid, (size_t)2 * nB * H * 4, true))
         return 1;
     for (int i = 0; i < 5; ++i)
-        if (dev_alloc(e, (void**)&e->hb[i], (size_t)nB * H * 4, true)) return 1;
+        if (dev_alloc(e, (void**)&e->hb[i], (size_t)2 * nB * H * 4, true)) return 1;
     if (dev_alloc(e, (void**)&e->xcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->lncls, (size_t)2 * nB * H * 4, true) ||
         dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->acls, (size_t)2 * nB * H * 4, true) ||
         dev_alloc(e, (void**)&e->h1cls, (size_t)2 * nB * e->Mdim * 4, true))
@@ -473,29 +474,34 @@ int vtq_profile_collect(vtq_handle e, double* ms_sum, int64_t* launches) {
     return 0;
 }
 
-int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
-                const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
+// nimg = 2: q_out[B] for (ref, dist); nimg = 3: q_out[2B] = scores of (ref, dist1) then (ref, dist2) with ref encoded once
+static int forward_impl(vtq_handle e, int nimg, const float* const* patches, const float* const* pos, const float* const* scales,
+                        int32_t B, int32_t N, float* q_out, void* stream) {
     if (!e) return fail("vtq_forward: null handle");
-    if (!patches_ref || !patches_dist || !pos_ref || !pos_dist || !q_out) return fail("vtq_forward: null tensor");
+    for (int k = 0; k < nimg; ++k)
+        if (!patches[k] || !pos[k]) return fail("vtq_forward: null tensor");
+    if (!q_out) return fail("vtq_forward: null output");
     if (B < 1 || N < 1) return fail("vtq_forward: B=%d N=%d", B, N);
     const vtq_config& c = e->cfg;
     const bool use_scales = c.num_scales > 1;
-    if (use_scales && (!scales_ref || !scales_dist))
-        return fail("Model uses scale embedding but scales is passed as None.");   // transformer.py:547-548
+    if (use_scales)
+        for (int k = 0; k < nimg; ++k)
+            if (!scales[k]) return fail("Model uses scale embedding but scales is passed as None.");   // transformer.py:547-548
     for (auto& kv : e->slots)
         if (!kv.second.loaded) return fail("vtq_forward: weight '%s' was never loaded", kv.first.c_str());
-    if (reserve(e, B, N)) return 1;
+    if (reserve(e, (nimg * B + 1) / 2, N)) return 1;       // capacity is kept in units of sequence pairs
+    const int ndist = nimg - 1, HB = ndist * B;            // head batch
     hipStream_t s = (hipStream_t)stream;
-    const Geometry g = geometry(e, B, N);
+    const Geometry g = geometry(e, B, N, nimg);
     const int H = e->H, T = e->T, ns = e->nsplit;
     const int L = c.num_layers;
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
-        HIP_TRY(launch_pack_patches(patches_ref, patches_dist, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, ns, s));
-        HIP_TRY(launch_embed_index(pos_ref, pos_dist, use_scales ? scales_ref : nullptr, use_scales ? scales_dist : nullptr, e->pidx,
-                                   e->sidx, e->row_map, B, N, (int)g.P_pad, g.S_pad, T, c.pos_grid, c.num_scales, s));
+        HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, ns, s));
+        HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.S_pad, T,
+                                   c.pos_grid, c.num_scales, s));
         HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.S_pad, H, (int)e->rows_alloc, s));
         HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.S_pad, T, H, s));
     }
@@ -541,8 +547,8 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
     {
         Prof p(e, s, VTQ_K_HEAD);
         float* d = e->hb[0];
-        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, 1, H, s));
-        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, g.S_pad, H, s));
+        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, 1, H, s));
+        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.S_pad, H, s));
         if (c.calibrate) {
             float* xr = e->hb[0];       // residual-group input
             float* xr_next = e->hb[1];
@@ -551,20 +557,35 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
                 const float* y = xr;
                 float* yo = y0;
                 for (auto& r : R.rcabs) {
-                    HIP_TRY(launch_rcab(y, r.slope, r.wcat, r.bcat, r.wu, r.bu, cb, e->hhid, yo, B, H, c.ca_hidden, s));
+                    HIP_TRY(launch_rcab(y, r.slope, r.wcat, r.bcat, r.wu, r.bu, cb, e->hhid, yo, HB, H, c.ca_hidden, s));
                     y = yo;
                     yo = (yo == y0) ? y1 : y0;
                 }
-                HIP_TRY(launch_small_linear(y, R.w, R.b, nullptr, nullptr, xr, xr_next, B, H, H, s));
+                HIP_TRY(launch_small_linear(y, R.w, R.b, nullptr, nullptr, xr, xr_next, HB, H, H, s));
                 float* t = xr; xr = xr_next; xr_next = t;
             }
-            HIP_TRY(launch_small_linear(xr, e->qdw, e->qdb, nullptr, nullptr, nullptr, xr_next, B, H, H, s));
+            HIP_TRY(launch_small_linear(xr, e->qdw, e->qdb, nullptr, nullptr, nullptr, xr_next, HB, H, H, s));
             d = xr_next;
         }
-        HIP_TRY(launch_small_linear(d, e->p1w, e->p1b, nullptr, e->p2a, nullptr, e->hhid, B, H / 4, H, s));
-        HIP_TRY(launch_small_linear(e->hhid, e->p4w, e->p4b, nullptr, nullptr, nullptr, q_out, B, 1, H / 4, s));
+        HIP_TRY(launch_small_linear(d, e->p1w, e->p1b, nullptr, e->p2a, nullptr, e->hhid, HB, H / 4, H, s));
+        HIP_TRY(launch_small_linear(e->hhid, e->p4w, e->p4b, nullptr, nullptr, nullptr, q_out, HB, 1, H / 4, s));
     }
     return 0;
+}
+
+int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
+                const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
+    const float* p[2] = {patches_ref, patches_dist};
+    const float* ps[2] = {pos_ref, pos_dist};
+    const float* sc[2] = {scales_ref, scales_dist};
+    return forward_impl(e, 2, p, ps, sc, B, N, q_out, stream);
+}
+
+int vtq_forward_pairwise(vtq_handle e, const float* const* patches, const float* const* pos, const float* const* scales, int32_t B,
+                         int32_t N, float* q_out, void* stream) {
+    if (!patches || !pos) return fail("vtq_forward_pairwise: null argument");
+    const float* sc[3] = {scales ? scales[0] : nullptr, scales ? scales[1] : nullptr, scales ? scales[2] : nullptr};
+    return forward_impl(e, 3, patches, pos, sc, B, N, q_out, stream);
 }
 
 // ---- per-kernel entry points -------------------------------------------------------------------------------------

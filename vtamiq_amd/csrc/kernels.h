@@ -24,14 +24,13 @@ hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t 
 
 hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s);
 
-// patches (ref,dist) fp32 [B*N, K] each -> bf16 planes [rows_pad, K], rows >= 2*B*N zero-filled
-hipError_t launch_pack_patches(const float* ref, const float* dist, void* dst, int64_t plane, int BN, int K,
-                               int rows_pad, int nsplit, hipStream_t s);
+// nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> bf16 planes [rows_pad, K], rows >= nimg*B*N zero-filled
+hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int nsplit,
+                               hipStream_t s);
 
-// per patch row r in [0, rows_pad): pos index, scale index, destination row in the residual stream (or -1)
-hipError_t launch_embed_index(const float* pos_ref, const float* pos_dist, const float* sc_ref, const float* sc_dist,
-                              int* pidx, int* sidx, int* row_map, int B, int N, int rows_pad, int S_pad, int T,
-                              int grid, int num_scales, hipStream_t s);
+// per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1)
+hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
+                              int rows_pad, int S_pad, int T, int grid, int num_scales, hipStream_t s);
 
 // CLS (+pos row 0) and register tokens into rows [seq*S_pad, seq*S_pad + T)
 hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, int S_pad,
@@ -49,8 +48,8 @@ hipError_t launch_zero_pad_rows(float* x, int nseq, int S, int S_pad, int H, int
 // copy token rows (first T rows of each sequence) of x into trace[nseq][T][H]
 hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, int S_pad, int T, int H, hipStream_t s);
 
-// d[b] = gamma * (LN(x[row(b)]) - LN(x[row(B+b)]))  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
-hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B,
+// d[j*B + b] = gamma * (LN(x[row(b)]) - LN(x[row((j+1)*B + b)])), j < ndist  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
+hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
                              int S_pad, int H, hipStream_t s);
 
 // y[b][n] = post( sum_k W[n][k] * pre(x[b][k]) + bias[n] ) (+ res[b][n]);  pre/post: optional PReLU(slope ptr)

@@ -320,6 +320,40 @@ class VTAMIQ(nn.Module):
                     lib.vtq_set_token_trace(self._engine, None)
         return q, None
 
+    def forward_pairwise(self, patches, pos, scales):
+        """Pairwise items: `patches = (p_ref, p_dist1, p_dist2)` etc.  Returns (q1, q2) == what two calls
+        `self((p_ref, p_dist1), ...)[0]`, `self((p_ref, p_dist2), ...)[0]` give (train.py:286-287), bit for bit, with the
+        reference image encoded once: 3B sequences instead of 4B."""
+        if self.training:
+            raise NotImplementedError("the MI355X engine implements the eval/no-grad forward only: call model.eval()")
+        if len(patches) != 3 or len(pos) != 3:
+            raise ValueError("forward_pairwise expects (ref, dist1, dist2) triplets")
+        device = patches[0].device
+        if device.type != "cuda":
+            raise RuntimeError("VTAMIQ (vtamiq_amd) runs on an MI355X only: move the model and inputs to 'cuda'. "
+                               "There is no CPU fallback on the product path.")
+        B, N = patches[0].shape[:2]
+        for t in patches:
+            if tuple(t.shape) != (B, N, 3, self.spec.patch_size, self.spec.patch_size):
+                raise ValueError(f"patches must be three (B,N,3,P,P) tensors, got {tuple(t.shape)}")
+        for t in pos:
+            if tuple(t.shape) != (B, N, 2):
+                raise ValueError("pos must be three (B,N,2) tensors")
+        use_scales = self.spec.use_scale_embedding
+        if use_scales and (scales is None or any(t is None for t in scales)):
+            raise ValueError("Model uses scale embedding but scales is passed as None.")
+        with torch.cuda.device(device):
+            lib = self._ensure_engine(device)
+            pt = [self._prep(t, device) for t in patches]
+            ps = [self._prep(t, device) for t in pos]
+            sc = [self._prep(t, device) for t in scales] if use_scales else None
+            q = torch.empty(2 * B, device=device, dtype=torch.float32)
+            arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.vtq_forward_pairwise(self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N,
+                                                q.data_ptr(), stream))
+        return q[:B], q[B:]
+
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------
     def profile_enable(self, classes):
         mask = 0

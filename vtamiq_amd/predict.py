@@ -6,6 +6,18 @@ that a validation loop written against train.py works unchanged with the MI355X 
 from __future__ import annotations
 
 import torch
+from torch import nn
+
+
+class PreferenceModule(nn.Module):
+    """modules/vtamiq/common.py:5-14 -- sigmoid(p * (q2 - q1)) for pairwise datasets (state_dict key: "p")."""
+
+    def __init__(self, weight=1.):
+        super().__init__()
+        self.p = nn.Parameter(torch.as_tensor(weight, dtype=torch.float32).reshape(-1))
+
+    def forward(self, q1, q2):
+        return torch.sigmoid(self.p * (q2 - q1)).flatten()
 
 
 def get_data_tuple(batch, device):
@@ -36,10 +48,16 @@ def predict(model, pref_module, data, is_pairwise, output_feats, use_scales):
         pref, pdist1, pdist2 = split_per_image(patches)
         posref, posdist1, posdist2 = split_per_image(pos)
         scalesref, scalesdist1, scalesdist2 = split_per_image(scales) if use_scales else (None, None, None)
-        out1 = model((pref, pdist1), (posref, posdist1), (scalesref, scalesdist1))
-        out2 = model((pref, pdist2), (posref, posdist2), (scalesref, scalesdist2))
-        q1, q2 = out1[0], out2[0]
-        feats = (out1[1], out2[1]) if output_feats else None
+        if hasattr(model, "forward_pairwise"):
+            # same scores as the two calls of train.py:286-287, with the shared reference image encoded once
+            q1, q2 = model.forward_pairwise((pref, pdist1, pdist2), (posref, posdist1, posdist2),
+                                            (scalesref, scalesdist1, scalesdist2) if use_scales else None)
+            feats = (None, None) if output_feats else None
+        else:
+            out1 = model((pref, pdist1), (posref, posdist1), (scalesref, scalesdist1))
+            out2 = model((pref, pdist2), (posref, posdist2), (scalesref, scalesdist2))
+            q1, q2 = out1[0], out2[0]
+            feats = (out1[1], out2[1]) if output_feats else None
         if pref_module is not None:
             q_p = pref_module(q1, q2)
         else:
