@@ -138,6 +138,20 @@ int  vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane,
 int  vtq_k_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope, const float* post_slope,
                         const float* res, float* y, int32_t B, int32_t N, int32_t K, void* stream);
 
+/* ---- on-device image -> patch tensor; replaces the CPU loader's transform_img (data/utils.py:76-94) and the
+ * gather / position / pyramid part of get_iqa_patches (data/patch_sampling.py:529-611) for GIVEN sample coordinates ---------- */
+/* images uint8 [NI, H, W, 3] -> out fp32 [NI, 3, H, W] = ((x / 255) - mean[c]) / std[c]; flips: DEVICE int32 [NI][2] = (hflip, vflip)
+ * or NULL; mean/std: HOST float[3]. */
+int  vtq_k_image_normalize(const uint8_t* images, float* out, int32_t NI, int32_t H, int32_t W, const int32_t* flips,
+                           const float* mean, const float* std_, void* stream);
+/* torch.nn.AvgPool2d(2): in [NC, H, W] -> out [NC, H/2, W/2]. */
+int  vtq_k_avgpool2(const float* in, float* out, int32_t NC, int32_t H, int32_t W, void* stream);
+/* levels: HOST array of nlevels (<= 4) DEVICE pointers to [NI, 3, hs[l], ws[l]]; samples DEVICE int32 [NI, N, 2] (row, col at the
+ * patch's own scale); scale_ids DEVICE int32 [NI, N] or NULL (all scale 0).  Outputs: patches [NI, N, 3, 16, 16],
+ * pos [NI, N, 2], scales [NI, N] (fp32-cast ids, may be NULL). */
+int  vtq_k_gather_patches(const float* const* levels, const int32_t* hs, const int32_t* ws, int32_t nlevels, const int32_t* samples,
+                          const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

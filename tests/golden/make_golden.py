@@ -244,6 +244,42 @@ def run_npz():
     print("npz_ingest_tiny:", len(out), "arrays")
 
 
+def run_patches():
+    """the gather / position / pyramid part of the loader, pinned by the reference's get_iqa_patches driven by a
+    RECORDING sampler (deterministic coordinates; the sampler's RNG is out of scope)."""
+    _install_train_stubs()
+    from data import patch_sampling as PS
+    from oracle.patch_oracle import transform_img
+    rs = np.random.RandomState(11)
+    H, W, P = 160, 208, 16
+    imgs = [rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in range(2)]
+    imgs[1] = np.clip(imgs[0].astype(np.int32) + rs.randint(-20, 21, size=(H, W, 3)), 0, 255).astype(np.uint8)
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+        def compute_diff(self, imgs):
+            return None
+        def get_sample_params(self, h, w, ho, wo, diff=None, num_samples=1, debug=False):
+            smp = np.stack([rs.randint(0, h - ho + 1, size=num_samples), rs.randint(0, w - wo + 1, size=num_samples)]).astype(np.int64)
+            self.calls.append((h, w, smp))
+            return smp
+
+    out = {"img0": imgs[0], "img1": imgs[1]}
+    for tag, aligned, flips in (("aligned", True, (False, False)), ("unaligned", False, (True, True))):
+        rec = Recorder()
+        tens = [transform_img(im, flips[0], flips[1]) for im in imgs]
+        patches, pos, scales = PS.get_iqa_patches(imgs, tens, 45, P, rec, 3, scale_num_samples_ratio=1.75,
+                                                  use_aligned_patches=aligned)
+        out[f"{tag}/patches"], out[f"{tag}/pos"], out[f"{tag}/scales"] = patches.numpy(), pos.numpy(), scales.numpy()
+        out[f"{tag}/flips"] = np.array(flips, dtype=np.int32)
+        out[f"{tag}/ncalls"] = np.array(len(rec.calls))
+        for i, (h, w, smp) in enumerate(rec.calls):
+            out[f"{tag}/call{i}/hw"] = np.array([h, w]); out[f"{tag}/call{i}/samples"] = smp
+    np.savez_compressed(os.path.join(HERE, "patches_gather.npz"), **out)
+    print("patches_gather:", {k: v.shape for k, v in out.items() if k.endswith("patches")})
+
+
 def main():
     sys.path.insert(0, REF)
     _install_stubs()
@@ -267,6 +303,7 @@ def main():
     run_ops()
     run_npz()
     run_plumbing()
+    run_patches()
 
 
 if __name__ == "__main__":

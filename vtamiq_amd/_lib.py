@@ -47,6 +47,11 @@ SIGNATURES = {
     "vtq_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
     "vtq_k_small_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "vtq_k_image_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), C.c_void_p]),
+    "vtq_k_avgpool2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "vtq_k_gather_patches": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
 }

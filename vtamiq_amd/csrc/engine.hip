@@ -623,4 +623,23 @@ int vtq_k_small_linear(const float* x, const float* W, const float* bias, const 
     return 0;
 }
 
+int vtq_k_image_normalize(const uint8_t* images, float* out, int32_t NI, int32_t H, int32_t W, const int32_t* flips, const float* mean,
+                          const float* std_, void* stream) {
+    if (!images || !out || !mean || !std_ || NI < 1 || H < 1 || W < 1) return fail("vtq_k_image_normalize: bad argument");
+    HIP_TRY(launch_image_normalize(images, out, NI, H, W, flips, mean, std_, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_avgpool2(const float* in, float* out, int32_t NC, int32_t H, int32_t W, void* stream) {
+    HIP_TRY(launch_avgpool2(in, out, NC, H, W, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_gather_patches(const float* const* levels, const int32_t* hs, const int32_t* ws, int32_t nlevels, const int32_t* samples,
+                         const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, void* stream) {
+    if (!levels || !hs || !ws || !samples || !patches || !pos) return fail("vtq_k_gather_patches: null argument");
+    HIP_TRY(launch_gather_patches(levels, hs, ws, nlevels, samples, scale_ids, patches, pos, scales, NI, N, (hipStream_t)stream));
+    return 0;
+}
+
 }  // extern "C"

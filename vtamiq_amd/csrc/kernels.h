@@ -71,4 +71,11 @@ hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, in
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
                                 int nsplit, hipStream_t s);
 
+// ---- on-device image -> patch tensor (patches.hip) -------------------------------------------------------
+hipError_t launch_image_normalize(const uint8_t* in, float* out, int NI, int H, int W, const int* flips, const float* mean, const float* sd,
+                                  hipStream_t s);
+hipError_t launch_avgpool2(const float* in, float* out, int NC, int H, int W, hipStream_t s);
+hipError_t launch_gather_patches(const float* const* levels, const int* hs, const int* ws, int nlevels, const int* samples,
+                                 const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s);
+
 }  // namespace vtq
