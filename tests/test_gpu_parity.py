@@ -211,3 +211,26 @@ def test_weight_reload_is_seen():
         q3 = model(p, ps, sc)[0]
     assert not torch.equal(q1, q2)
     assert torch.equal(q1, q3)
+
+
+@pytest.mark.parametrize("B,N,extra,variant,scales", [(1, 8, 0, "ViT-B16", 0), (5, 77, 0, "ViT-B16", 0), (3, 200, 8, "ViT-B16", 0),
+                                                      (1, 130, 0, "ViT-L16", 3), (7, 56, 3, "ViT-B16", 2), (2, 119, 8, "ViT-B16", 0)])
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, parts, monkeypatch):
+    """Edge shapes: B = 1 / odd B (part-batches fall back to one stream), S = N + T hitting 9 / 78 / 209 / 128 exactly (S == S_pad),
+    register tokens, 2- and 3-scale embeddings, ViT-L; oracle on the host as the checker."""
+    monkeypatch.setenv("VTQ_PARTS", parts)
+    kw = dict(vit_config=dict(variant=variant, num_keep_layers=2, num_extra_tokens=extra, num_scales=scales, use_layer_scale=bool(extra)),
+              num_rgs=2, num_rcabs=2, ca_reduction=16)
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="bf16x3")
+    sd = synth.make_state_dict(m.spec, 40 + B)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    patches, pos, sc = synth.make_inputs(m.spec, B, N, 50 + N, aligned=bool(B & 1))
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    with torch.no_grad():
+        q = m(p, ps, s3)[0].cpu().numpy()
+    cp, cps, cs = split_inputs(patches, pos, sc)
+    q_ref = O.vtamiq_forward(O.to_torch(sd), m.spec, cp, cps, cs)[0].numpy()
+    assert q.shape == (B,) and np.isfinite(q).all()
+    assert gate(q, q_ref, 1e-3), rel_err(q, q_ref)
