@@ -158,7 +158,8 @@ def main():
     assert q.shape == (global_batch,) and bool(torch.isfinite(q).all())
     pairs_per_s = global_batch * a.steps / dt
     f_pair = spec.flops_per_pair(N)                      # algorithmic (SURVEY 8d / BASELINE.md)
-    f_exec = spec.flops_per_pair_executed(N, cls_prune=os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1")
+    pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
+    f_exec = spec.flops_per_pair_executed(N, cls_prune=pruned)
     S = spec.seq_len(N)
 
     out = {
@@ -176,22 +177,35 @@ def main():
         "forward_mfma_frac": pairs_per_s / world * f_exec / (PEAK_BF16_TFLOPS * 1e12),
         "flops_per_pair": f_pair, "flops_per_pair_executed": f_exec,
     }
-    if prof and prof[1] > 0:
-        ms_sum, launches = prof
-        # fc1 GEMM launches per step: (layers that run the full MLP) x (part-batches); all launches have the same shape
-        pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
-        full_layers = spec.num_layers - (1 if pruned else 0)
-        per_step = launches / a.steps
+
+    def roofline_of(prof_entry, steps, note):
+        ms_sum, launches = prof_entry
+        full_layers = spec.num_layers - (1 if pruned else 0)       # fc1 GEMM launches per step = full layers x part-batches
+        per_step = launches / steps
         flops_launch = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim * full_layers / per_step    # algorithmic, unpadded rows
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
         traffic = fc1_traffic(a.precision, B)
-        out["roofline"] = {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1 of every full layer)",
-                           "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                           "traffic": traffic * full_layers / per_step if traffic else None,
-                           "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
-                           "flops_per_launch": flops_launch,
-                           "note": "HIP events on the launch stream inside the timed region; with 2 part-batches on 2 streams a launch "
-                                   "covers half the rows and shares the chip with the other stream's kernels"}
+        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1 of every full layer)",
+                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                "traffic": traffic * full_layers / per_step if traffic else None, "avg_launch_ms": ms_sum / launches,
+                "launches": int(launches), "launches_per_step": per_step, "flops_per_launch": flops_launch,
+                # bf16x3 issues 3 bf16 MFMAs per algorithmic product, so its algorithmic frac is capped at 1/3
+                "mfma_issue_frac": ach * (3 if a.precision == "bf16x3" else 1) / PEAK_BF16_TFLOPS, "note": note}
+
+    if prof and prof[1] > 0:
+        in_region = roofline_of(prof, a.steps, "HIP events inside the timed region of `value`: two part-batches run on two streams, so a "
+                                "launch covers half the rows and shares the chip with the other stream's kernels")
+        # the same kernel alone on the chip: a second timed region with ONE part-batch (full-batch launches on one stream)
+        os.environ["VTQ_PARTS"] = "1"
+        model_iso = make_model(a.precision)
+        iso_steps = max(3, a.steps // 2)
+        _, _, prof_iso = run(model_iso, iso_steps, 2, DOM)      # the engine is created lazily on the first forward
+        os.environ.pop("VTQ_PARTS")
+        out["roofline"] = roofline_of(prof_iso, iso_steps, "HIP events on the launch stream over a timed region with one part-batch "
+                                      "(VTQ_PARTS=1): the kernel alone on the chip, full-batch launches")
+        out["roofline"]["in_value_region"] = {k: in_region[k] for k in ("achieved", "frac", "avg_launch_ms", "launches_per_step", "note")}
+        del model_iso
+        torch.cuda.empty_cache()
     if rank == 0 and not a.no_second_mode:
         other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         del model
@@ -199,9 +213,9 @@ def main():
     if not a.no_second_mode:
         other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         model2 = make_model(other)
-        dt2, q2, _ = run(model2, max(3, a.steps // 2), 2)
-        out["other_mode"] = {"numerics": other, "value": global_batch * max(3, a.steps // 2) / dt2, "unit": "image-pairs/s",
-                             "forward_mfma_frac": global_batch * max(3, a.steps // 2) / dt2 / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)}
+        dt2, q2, _ = run(model2, a.steps, a.warmup)
+        out["other_mode"] = {"numerics": other, "value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
+                             "forward_mfma_frac": global_batch * a.steps / dt2 / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)}
     else:
         q2 = None
     if rank == 0:
