@@ -124,6 +124,11 @@ int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int6
                 const float* bias, const float* gamma, float* x_f32,
                 void* out_bf16, int64_t o_plane, int32_t ldo, void* stream);
 
+/* HOST-only: the block order vtq_k_gemm uses for an [M, N] output (M, N multiples of 256): out[i] = (tile << 2) | kind with
+ * tile = row_tile * (N/256) + col_tile, kind 0 = 256x256 tile, 1 / 2 = its top / bottom 128 rows.  Returns the number of
+ * blocks (writes at most cap entries; out may be NULL), or -1 on a bad shape.  No GPU needed. */
+int  vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t* out, int32_t cap);
+
 /* LayerNorm(eps=1e-6) rows of x[rows, H] fp32 -> bf16 planes (transformer.py:253-254, 276, 281). */
 int  vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane,
                      int32_t rows, int32_t H, int32_t nsplit, void* stream);

@@ -121,3 +121,26 @@ def test_predict_pairwise_branch_matches_reference_semantics():
     assert torch.allclose(q_p, torch.sigmoid(2.0 * (q2 - q1)))
     _, q_p2, _ = predict(model, None, (torch.zeros(B), patches, pos, scales), True, False, False)
     assert torch.allclose(q_p2, torch.sigmoid(q1 - q2))
+
+
+def test_gemm_tile_schedule_covers_every_tile_once():
+    """The host-built block order of the GEMM (gemm.hip build_schedule): every 256x256 tile appears exactly once, either whole
+    or as its top AND bottom half; pure host code, callable without a GPU."""
+    import ctypes as C
+    import numpy as np
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    assert lib.vtq_k_gemm_schedule(100, 256, None, 0) == -1
+    for M, N in [(256, 256), (1024, 768), (16384, 768), (16384, 2304), (16384, 3072), (32768, 2304), (32768, 768), (33024, 1024),
+                 (65536, 4096)]:
+        n = lib.vtq_k_gemm_schedule(M, N, None, 0)
+        out = np.full(n, -1, np.int32)
+        assert lib.vtq_k_gemm_schedule(M, N, out.ctypes.data_as(C.c_void_p), n) == n
+        nt = (M // 256) * (N // 256)
+        tile, kind = out >> 2, out & 3
+        assert tile.min() >= 0 and tile.max() < nt and kind.max() <= 2
+        whole = np.bincount(tile[kind == 0], minlength=nt)
+        top = np.bincount(tile[kind == 1], minlength=nt)
+        bot = np.bincount(tile[kind == 2], minlength=nt)
+        assert ((whole == 1) & (top == 0) & (bot == 0) | (whole == 0) & (top == 1) & (bot == 1)).all(), (M, N)
+        assert n == nt + int((kind == 1).sum())

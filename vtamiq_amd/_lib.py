@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvtamiq_hip.so")
+LIB_PATH = os.environ.get("VTQ_LIB_PATH") or os.path.join(_HERE, "libvtamiq_hip.so")   # override: kernel A/B builds in tools/
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -52,6 +52,7 @@ SIGNATURES = {
     "vtq_k_avgpool2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_gather_patches": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "vtq_k_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
 }

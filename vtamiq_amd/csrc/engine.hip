@@ -594,6 +594,14 @@ int vtq_k_split_bf16(const float* src, void* dst, int64_t plane_stride, int64_t 
     return 0;
 }
 
+int vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t* out, int32_t cap) {
+    if (M < 256 || N < 256 || M % 256 || N % 256) return -1;
+    const std::vector<int> v = gemm_tile_schedule(M / 256, N / 256);
+    if (out)
+        for (size_t i = 0; i < v.size() && (int32_t)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
 int vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t N, int32_t K,
                int32_t nsplit, int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out_bf16,
                int64_t o_plane, int32_t ldo, void* stream) {

@@ -20,13 +20,18 @@
 //                                                 B: read A1       | 32 (x3: 48) MFMAs on quadrants (1,1),(1,0)
 //       LDS reads are retired (lgkmcnt(0)) BEFORE the phase barrier: the MFMA cluster starts right after the barrier and a
 //       region may be re-staged one phase after its last read.  Measured fixed cost per barrier interval ~250 cycles, so
-//       the longer clusters lift MFMA utilisation over the 4-phase form (16 MFMAs per interval; VTQ_GEMM_VARIANT=4).
+//       the longer clusters lift MFMA utilisation over a 4-phase form (16 MFMAs per interval; measured, removed).
 //   * Operands are swapped in the MFMA (W fragment as A-operand): a lane holds 4 consecutive output columns of one row.
 //   * Epilogues stage through LDS so every global access is a full row segment, 16 bytes per lane.
 //   * NSPLIT == 3 ("bf16x3"): A and W arrive as hi/lo bf16 planes; each product is hi*hi + hi*lo + lo*hi into the same fp32
 //     accumulator (3 MFMAs per 4 fragment reads); BK is 32 instead of 64 so regions keep their 16 KiB.
-//   * Workgroup ids are remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2.
+//   * Workgroups follow a host-built tile schedule (build_schedule): XCD-contiguous tile runs whose last round is filled
+//     with 128-row half tiles.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "dev_common.h"
 #include "kernels.h"
@@ -58,7 +63,7 @@ __device__ __forceinline__ void wait_dma(int n) {
 }
 
 // ---- shared epilogue of the ping-pong kernels -------------------------------------------------------------------------
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, int MH>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
                                             int fr, int fq, int64_t m0, int n0) {
     // ---- epilogue ------------------------------------------------------------------------------------------------------
@@ -83,7 +88,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -120,10 +125,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                 const int c16 = tid & 31, r0 = tid >> 5;
                 bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
 #pragma unroll
-                for (int ps = 0; ps < 16; ++ps) {
+                for (int ps = 0; ps < 8 * MH; ++ps) {
                     const int row = ps * 16 + r0;
                     const uint4 v = *(const uint4*)(smem + row * RS + c16 * 16);
-                    *(uint4*)(og + (int64_t)row * p.ldo) = v;
+                    store_nt16(og + (int64_t)row * p.ldo, v);
                 }
             }
             if (pl + 1 < NP) __syncthreads();
@@ -131,7 +136,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
     } else if constexpr (EPI == EPI_RESID) {
         constexpr int RS = 1040;                        // 256 fp32 + 16 B pad (odd multiple of 16: conflict-free b128 writes)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
+        for (int mh = 0; mh < MH; ++mh) {
             if (mh) __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -166,7 +171,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         }
     } else {  // EPI_EMBED: scattered rows + table gathers, once per forward: direct from registers
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int64_t m = m0 + mh * 128 + wr * 64 + mi * 16 + fr;
@@ -200,15 +205,24 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 }
 
 // ---- common prologue of both schedules ----------------------------------------------------------------------------------
-struct Tile { int64_t m0; int n0; };
-__device__ __forceinline__ Tile tile_of_block(int M, int N) {
-    const int ntn = N / 256, ntm = M / 256;
-    const int nwg = ntn * ntm;
-    int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective XCD-contiguous remap
+// Tile descriptor of a workgroup.  With a schedule (GemmArgs::sched, built on the host by build_schedule below) block b runs
+// sched[b] = (tile << 2) | kind, kind 0 = full 256x256 tile, 1 / 2 = top / bottom 128-row half of it; without one the blocks
+// are remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2.
+struct Tile { int64_t m0; int n0; int half; };
+__device__ __forceinline__ Tile tile_of_block(const GemmArgs& p) {
+    const int ntn = p.N / 256, ntm = p.M / 256;
+    int bid = blockIdx.x, kind = 0;
+    if (p.sched) {
+        const int d = p.sched[bid];
+        bid = d >> 2;
+        kind = d & 3;
+    } else {
+        const int nwg = ntn * ntm;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective XCD-contiguous remap
+    }
     const int tm = bid / ntn, tn = bid - tm * ntn;
-    return Tile{(int64_t)tm * 256, tn * 256};
+    return Tile{(int64_t)tm * 256 + (kind == 2 ? 128 : 0), tn * 256, kind != 0};
 }
 
 #define VTQ_PP_COMMON()                                                                                                  \
@@ -223,7 +237,7 @@ __device__ __forceinline__ Tile tile_of_block(int M, int N) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                            \
     const int wr = wave >> 2, wc = wave & 3;                                                                              \
     const int fr = lane & 15, fq = lane >> 4;                                                                             \
-    const Tile tl = tile_of_block(p.M, p.N);                                                                              \
+    const Tile tl = tile_of_block(p);                                                                              \
     const int64_t m0 = tl.m0;                                                                                             \
     const int n0 = tl.n0;                                                                                                 \
     const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;                                                          \
@@ -294,7 +308,7 @@ __device__ __forceinline__ Tile tile_of_block(int M, int N) {
     };
 
 // =====================================================================================================================
-// 2-phase ping-pong schedule (default).
+// 2-phase ping-pong schedule.
 //   DMA groups in issue order: g = 2k: {A0, W0, W1} of K tile k (6 DMA instructions); g = 2k+1: {A1} of tile k (2).
 //   prologue issues groups 0,1,2; phase A(kt) issues group 2kt+3, phase B(kt) issues group 2kt+4.
 //   phase A(kt) reads A0,W0,W1 (waited for in B(kt-1) / prologue) and waits for group 2kt+1 (read in B(kt));
@@ -302,6 +316,10 @@ __device__ __forceinline__ Tile tile_of_block(int M, int N) {
 //   WAR: a region is read (and the read retired by lgkmcnt(0)) before its reader passes the phase barrier; the other wave
 //        group re-stages it in the NEXT phase, i.e. after that barrier.  RAW: a group is waited for by every wave one phase
 //        before the first read, and both wave groups' waits precede the barrier that opens the reading phase.
+//
+// Half tiles (128 x 256, rows of A half 0 only) are phase A alone: one group {A0, W0, W1} per K tile on a ring of THREE
+// 48 KiB buffers, tile kt+2 staged in phase kt into the buffer read in phase kt-1 (same WAR/RAW argument), vmcnt(6) steady.
+// They exist for the tile schedule (build_schedule), which fills the last round of a launch in half-tile granules.
 template <int NSPLIT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     VTQ_PP_COMMON()
@@ -318,111 +336,176 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                              \
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- prologue: groups 0, 1, 2 --------------------------------------------------------------------------------
-    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
-    if (nkt > 1) { stage(1, 0); stage(1, 1); stage(1, 2); }
-    wait_dma(nkt > 1 ? 8 : 2);
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
+    if (!tl.half) {
+        // ---- prologue: groups 0, 1, 2 ----------------------------------------------------------------------------
+        stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+        if (nkt > 1) { stage(1, 0); stage(1, 1); stage(1, 2); }
+        wait_dma(nkt > 1 ? 8 : 2);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* buf = smem + (kt & 1) * BUF_B;
-        // ---- phase A ------------------------------------------------------------------------------------------------
-        read_b(buf + 1 * REG_B, fb0);
-        read_a(buf + 0 * REG_B);
-        read_b(buf + 2 * REG_B, fb1);
-        if (kt + 1 < nkt) stage(kt + 1, 3);
-        VTQ_SYNC_OPEN(kt + 1 < nkt ? 8 : 0)
-        mma(acc[0][0], fb0);
-        mma(acc[0][1], fb1);
-        VTQ_SYNC_CLOSE()
-        // ---- phase B ------------------------------------------------------------------------------------------------
-        read_a(buf + 3 * REG_B);
-        if (kt + 2 < nkt) { stage(kt + 2, 0); stage(kt + 2, 1); stage(kt + 2, 2); }
-        VTQ_SYNC_OPEN(kt + 2 < nkt ? 8 : (kt + 1 < nkt ? 2 : 0))
-        mma(acc[1][1], fb1);
-        mma(acc[1][0], fb0);
-        VTQ_SYNC_CLOSE()
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* buf = smem + (kt & 1) * BUF_B;
+            // ---- phase A --------------------------------------------------------------------------------------------
+            read_b(buf + 1 * REG_B, fb0);
+            read_a(buf + 0 * REG_B);
+            read_b(buf + 2 * REG_B, fb1);
+            if (kt + 1 < nkt) stage(kt + 1, 3);
+            VTQ_SYNC_OPEN(kt + 1 < nkt ? 8 : 0)
+            mma(acc[0][0], fb0);
+            mma(acc[0][1], fb1);
+            VTQ_SYNC_CLOSE()
+            // ---- phase B --------------------------------------------------------------------------------------------
+            read_a(buf + 3 * REG_B);
+            if (kt + 2 < nkt) { stage(kt + 2, 0); stage(kt + 2, 1); stage(kt + 2, 2); }
+            VTQ_SYNC_OPEN(kt + 2 < nkt ? 8 : (kt + 1 < nkt ? 2 : 0))
+            mma(acc[1][1], fb1);
+            mma(acc[1][0], fb0);
+            VTQ_SYNC_CLOSE()
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+        pp_epilogue<NSPLIT, EPI, 2>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
+    } else {
+        constexpr int BUF_H = 3 * REG_B;
+        auto stage_h = [&](int kt, int slot) {             // {A0, W0, W1} of K tile kt into ring slot
+            char* dst = smem + slot * BUF_H + wave * 1024;
+            const bf16* ab = Ag + kt * BK;
+            const bf16* w0 = Wg + kt * BK;
+            const bf16* w1 = Wg + (int64_t)128 * p.K + kt * BK;
+            glds16(ab + a_off[0], dst);
+            glds16(ab + a_off[1], dst + 8192);
+            glds16(w0 + w_off[0], dst + REG_B);
+            glds16(w0 + w_off[1], dst + REG_B + 8192);
+            glds16(w1 + w_off[0], dst + 2 * REG_B);
+            glds16(w1 + w_off[1], dst + 2 * REG_B + 8192);
+        };
+        stage_h(0, 0);
+        if (nkt > 1) stage_h(1, 1);
+        wait_dma(nkt > 1 ? 6 : 0);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        int slot = 0;                                      // kt % 3
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* buf = smem + slot * BUF_H;
+            read_b(buf + 1 * REG_B, fb0);
+            read_a(buf + 0 * REG_B);
+            read_b(buf + 2 * REG_B, fb1);
+            const int nslot = slot == 0 ? 2 : slot - 1;    // (kt + 2) % 3
+            if (kt + 2 < nkt) stage_h(kt + 2, nslot);
+            VTQ_SYNC_OPEN(kt + 2 < nkt ? 6 : 0)
+            mma(acc[0][0], fb0);
+            mma(acc[0][1], fb1);
+            VTQ_SYNC_CLOSE()
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        pp_epilogue<NSPLIT, EPI, 1>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
 #undef VTQ_SYNC_OPEN
 #undef VTQ_SYNC_CLOSE
-    pp_epilogue<NSPLIT, EPI>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
 }
 
 // =====================================================================================================================
-// 4-phase ping-pong schedule (VTQ_GEMM_VARIANT=4; kept for A/B): one quadrant (16 / 24 MFMAs) per phase, half-tiles issued
-// one per phase in the order A0,W0,W1,A1, six half-tiles of lead, reads retired after the barrier.
-template <int NSPLIT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) {
-    VTQ_PP_COMMON()
-    const int nseq = 4 * nkt;
-    auto stage_seq = [&](int s, int r) { if (s < nseq) stage(s >> 2, r); };
-#define VTQ_PHASE_SYNC(q)                                                         \
-    wait_dma(2 * (nseq - (q) - 3 < 4 ? nseq - (q) - 3 : 4));                      \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_setprio(1);
-#define VTQ_PHASE_END()                                                           \
-    __builtin_amdgcn_s_setprio(0);                                                \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    __builtin_amdgcn_s_barrier();                                                 \
-    __builtin_amdgcn_sched_barrier(0);
+// Tile schedule (host).  Workgroups are dispatched in blockIdx order, round-robin over the 8 XCDs, one per CU (LDS-bound),
+// and a CU takes the next block when it retires one.  The schedule keeps each XCD on a contiguous run of tiles (A row panels
+// and W stay in its L2) and ends the run with 128-row HALF tiles, so the last round is filled in half-tile granules: N = 768
+// GEMMs are 1.5 rounds at 64 pairs, qkv 4.5 -- measured -10 % (out-proj), -6 % (fc2), -3 % (qkv) against whole tiles only.
+// The number of split tiles is chosen by simulating the greedy dispatch per XCD.  Output never depends on the schedule:
+// every element is accumulated over K in the same order in both tile forms.
+// (Starting half of the CUs on a half tile, to keep neighbours' epilogue write bursts out of phase, was measured too:
+//  no gain -- a write burst starves every CU's operand stream, not only the writers'.)
+constexpr int kXcds = 8, kCusPerXcd = 32;
+constexpr double kHalfCost = 0.57;              // measured: a launch of half tiles only takes 1.14x the whole-tile launch
 
-    stage_seq(0, 0); stage_seq(1, 1); stage_seq(2, 2); stage_seq(3, 3); stage_seq(4, 0); stage_seq(5, 1);
-    wait_dma(2 * (nseq >= 6 ? 4 : nseq - 2));
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* buf = smem + (kt & 1) * BUF_B;
-        const int q = 4 * kt;
-        read_b(buf + 1 * REG_B, fb0);
-        read_a(buf + 0 * REG_B);
-        stage_seq(q + 6, 2);
-        VTQ_PHASE_SYNC(q)
-        mma(acc[0][0], fb0);
-        VTQ_PHASE_END()
-        read_b(buf + 2 * REG_B, fb1);
-        stage_seq(q + 7, 3);
-        VTQ_PHASE_SYNC(q + 1)
-        mma(acc[0][1], fb1);
-        VTQ_PHASE_END()
-        read_a(buf + 3 * REG_B);
-        stage_seq(q + 8, 0);
-        VTQ_PHASE_SYNC(q + 2)
-        mma(acc[1][1], fb1);
-        VTQ_PHASE_END()
-        stage_seq(q + 9, 1);
-        VTQ_PHASE_SYNC(q + 3)
-        mma(acc[1][0], fb0);
-        VTQ_PHASE_END()
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef VTQ_PHASE_SYNC
-#undef VTQ_PHASE_END
-    pp_epilogue<NSPLIT, EPI>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
+double greedy_makespan(int n_full, int n_half) {
+    double cu[kCusPerXcd] = {0};
+    auto put = [&](double d) {
+        int best = 0;
+        for (int i = 1; i < kCusPerXcd; ++i) if (cu[i] < cu[best]) best = i;
+        cu[best] += d;
+    };
+    for (int i = 0; i < n_full; ++i) put(1.0);
+    for (int i = 0; i < n_half; ++i) put(kHalfCost);
+    double m = 0;
+    for (double v : cu) m = v > m ? v : m;
+    return m;
 }
 
-template <int NSPLIT, int EPI> hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 135168;                    // DMA ring 128 KiB; epilogue images 256x528 B / 128x1040 B
+// sequence of one XCD owning tiles [t0, t0 + cnt): whole tiles, then `tail` tiles as top/bottom halves
+void xcd_sequence(int t0, int cnt, std::vector<int>& out) {
+    static const bool all_halves = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return v && v[0] == '2'; }();   // measurement knob
+    int best_tail = 0;
+    double best = 1e30;
+    for (int tail = 0; tail <= cnt && tail <= 2 * kCusPerXcd; ++tail) {
+        const double m = greedy_makespan(cnt - tail, 2 * tail) + 1e-3 * tail;
+        if (m < best) { best = m; best_tail = tail; }
+    }
+    if (all_halves) best_tail = cnt;
+    for (int i = 0; i < cnt - best_tail; ++i) out.push_back((t0 + i) << 2);
+    for (int i = cnt - best_tail; i < cnt; ++i) { out.push_back(((t0 + i) << 2) | 1); out.push_back(((t0 + i) << 2) | 2); }
+}
+
+std::vector<int> build_schedule(int ntm, int ntn) {
+    const int nt = ntm * ntn, q = nt / kXcds, r = nt % kXcds;
+    std::vector<std::vector<int>> seq(kXcds);
+    size_t total = 0;
+    for (int x = 0; x < kXcds; ++x) {
+        const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        xcd_sequence(t0, q + (x < r ? 1 : 0), seq[x]);
+        total += seq[x].size();
+    }
+    std::vector<int> out;
+    out.reserve(total);
+    for (size_t j = 0; out.size() < total; ++j)             // block b -> XCD b % 8 while every XCD still has entries
+        for (int x = 0; x < kXcds; ++x)
+            if (j < seq[x].size()) out.push_back(seq[x][j]);
+    return out;
+}
+
+struct DevSched { int* dev; int n; };
+// process-wide cache keyed by the tile grid; entries are a few KiB and live until exit
+hipError_t schedule_for(int ntm, int ntn, DevSched& ds) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, DevSched> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({ntm, ntn});
+    if (it != cache.end()) { ds = it->second; return hipSuccess; }
+    const std::vector<int> h = build_schedule(ntm, ntn);
+    DevSched d{nullptr, (int)h.size()};
+    hipError_t e = hipMalloc(&d.dev, h.size() * sizeof(int));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(d.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);     // blocking; first launch of a shape only
+    if (e != hipSuccess) return e;
+    cache[{ntm, ntn}] = d;
+    ds = d;
+    return hipSuccess;
+}
+
+template <int NSPLIT, int EPI> hipError_t launch_t(GemmArgs a, hipStream_t s) {
+    constexpr int LDS = 147456;                    // full tiles: DMA ring 128 KiB, epilogue images 256x528 B; half tiles: 3 x 48 KiB
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_pp2_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)gemm_pp4_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
         configured = true;
     }
-    const int nwg = (a.M / 256) * (a.N / 256);
-    const char* v = getenv("VTQ_GEMM_VARIANT");
-    if (v && v[0] == '4') hipLaunchKernelGGL((gemm_pp4_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
-    else hipLaunchKernelGGL((gemm_pp2_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    static const bool use_sched = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return !(v && v[0] == '0'); }();
+    int nwg = (a.M / 256) * (a.N / 256);
+    a.sched = nullptr;
+    if (use_sched) {
+        DevSched ds;
+        hipError_t e = schedule_for(a.M / 256, a.N / 256, ds);
+        if (e != hipSuccess) return e;
+        a.sched = ds.dev;
+        nwg = ds.n;
+    }
+    hipLaunchKernelGGL((gemm_pp2_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
 }  // namespace
+
+std::vector<int> gemm_tile_schedule(int ntm, int ntn) { return build_schedule(ntm, ntn); }
 
 hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K % 64 || a.lda % 8 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;

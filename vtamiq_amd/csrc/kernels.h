@@ -1,6 +1,8 @@
 // Host-side launch prototypes of the gfx950 kernels (internal; the public ABI is include/vtamiq_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 namespace vtq {
@@ -18,9 +20,12 @@ struct GemmArgs {
     const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
     const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
     const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
+    const int* sched;                             // set by launch_gemm: tile schedule (gemm.hip build_schedule) or nullptr
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s);
+// block order of a (ntm x ntn)-tile GEMM: entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half (host only)
+std::vector<int> gemm_tile_schedule(int ntm, int ntn);
 
 hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s);
 
