@@ -157,6 +157,19 @@ int  vtq_k_avgpool2(const float* in, float* out, int32_t NC, int32_t H, int32_t 
 int  vtq_k_gather_patches(const float* const* levels, const int32_t* hs, const int32_t* ws, int32_t nlevels, const int32_t* samples,
                           const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, void* stream);
 
+/* ---- validation-loop reductions; fp64 like the reference's numpy arrays ------------------------------------ */
+/* average_over_repeats (train.py:398-400): q fp32 [R, N] (repeat-major, as the concatenated passes of do_validation) ->
+ * out fp64 [N] = mean over the R repeats, summed in repeat order. */
+int  vtq_k_repeat_mean(const float* q, double* out, int32_t R, int32_t N, void* stream);
+/* The fit-free part of compute_correlations (utils/misc/correlations.py:21-33) on two fp64 score vectors a, b [N]:
+ *   work[0:N], work[N:2N]  = normalize_array(a), normalize_array(b) (image_tools.py:17-21; plain copies when normalize == 0)
+ *   work[2N:3N], [3N:4N]   = their average-tie ranks
+ *   counts[0] = 2 (concordant - discordant pairs), counts[1] = 2 (pairs tied in a), counts[2] = 2 (pairs tied in b)   (exact)
+ *   out[0] = Spearman (Pearson of the ranks), out[1] = Pearson, out[2] = RMSE of the normalised vectors.
+ * work: DEVICE fp64 [4N]; counts: DEVICE int64 [3]; out: DEVICE fp64 [3].  The host finishes Kendall's tau-b from the counts. */
+int  vtq_k_rank_metrics(const double* a, const double* b, int32_t N, int32_t normalize, double* work, int64_t* counts, double* out,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

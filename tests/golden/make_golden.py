@@ -280,6 +280,40 @@ def run_patches():
     print("patches_gather:", {k: v.shape for k, v in out.items() if k.endswith("patches")})
 
 
+def run_validation_metrics():
+    """train.py:398-409 + utils/misc/correlations.py:21-52 on seeded scores: 3 cases (plain, heavy ties, repeats = 1)."""
+    _install_train_stubs()
+    import train as ref_train
+    rng = np.random.default_rng(2024)
+    out = {}
+    cases = [("mos", 37, 4, 8, 0.1), ("ties", 203, 3, 32, 0.02), ("single", 64, 1, 16, 0.0)]
+    for name, n, reps, bs, quant in cases:
+        q = rng.uniform(0.0, 1.0, n)
+        if quant:
+            q = np.round(q / quant) * quant                                   # MOS-like targets with ties
+        q = q.astype(np.float32)
+        ys, yp, flat_p = [], [], []
+        for r in range(reps):
+            pred = (0.7 * q + 0.1 + 0.08 * rng.standard_normal(n)).astype(np.float32)
+            if name == "ties":
+                pred = (np.round(pred * 20) / 20).astype(np.float32)          # ties in the predictions too
+            flat_p.append(pred)
+            for i in range(0, n, bs):
+                ys.append(torch.from_numpy(q[i:i + bs].copy()))
+                yp.append(torch.from_numpy(pred[i:i + bs].copy()))
+        corr = ref_train.compute_correlations_cat_flat(ys, yp, reps)
+        flat_p = np.concatenate(flat_p)
+        out[name + "_q"] = q
+        out[name + "_pred"] = flat_p                                           # [reps * n], pass-major
+        out[name + "_reps"] = reps
+        out[name + "_bs"] = bs
+        out[name + "_mean"] = ref_train.average_over_repeats(np.array(flat_p, dtype=float), reps) if reps > 1 else np.array(flat_p, dtype=float)
+        for k, v in corr.items():
+            out[name + "_" + k] = np.float64(v)
+        print("validation_metrics", name, {k: float(v) for k, v in corr.items()})
+    np.savez(os.path.join(HERE, "validation_metrics.npz"), **out)
+
+
 def main():
     sys.path.insert(0, REF)
     _install_stubs()
@@ -304,6 +338,7 @@ def main():
     run_npz()
     run_plumbing()
     run_patches()
+    run_validation_metrics()
 
 
 if __name__ == "__main__":

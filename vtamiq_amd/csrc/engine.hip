@@ -631,6 +631,20 @@ int vtq_k_small_linear(const float* x, const float* W, const float* bias, const 
     return 0;
 }
 
+int vtq_k_repeat_mean(const float* q, double* out, int32_t R, int32_t N, void* stream) {
+    if (!q || !out || R < 1 || N < 1) return fail("vtq_k_repeat_mean: bad argument");
+    HIP_TRY(launch_repeat_mean(q, out, R, N, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_rank_metrics(const double* a, const double* b, int32_t N, int32_t normalize, double* work, int64_t* counts, double* out,
+                       void* stream) {
+    if (!a || !b || !work || !counts || !out || N < 2) return fail("vtq_k_rank_metrics: bad argument");
+    HIP_TRY(launch_rank_metrics(a, b, N, normalize, work, work + N, work + 2 * (int64_t)N, work + 3 * (int64_t)N, (long long*)counts, out,
+                                (hipStream_t)stream));
+    return 0;
+}
+
 int vtq_k_image_normalize(const uint8_t* images, float* out, int32_t NI, int32_t H, int32_t W, const int32_t* flips, const float* mean,
                           const float* std_, void* stream) {
     if (!images || !out || !mean || !std_ || NI < 1 || H < 1 || W < 1) return fail("vtq_k_image_normalize: bad argument");

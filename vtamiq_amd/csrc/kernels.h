@@ -83,4 +83,9 @@ hipError_t launch_avgpool2(const float* in, float* out, int NC, int H, int W, hi
 hipError_t launch_gather_patches(const float* const* levels, const int* hs, const int* ws, int nlevels, const int* samples,
                                  const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s);
 
+// ---- validation reductions (metrics.hip) --------------------------------------------------------------------------------
+hipError_t launch_repeat_mean(const float* q, double* out, int R, int N, hipStream_t s);
+hipError_t launch_rank_metrics(const double* a, const double* b, int N, int normalize, double* aa, double* bb, double* ra, double* rb,
+                               long long* counts, double* out, hipStream_t s);
+
 }  // namespace vtq
