@@ -206,12 +206,10 @@ def main():
         out["roofline"]["in_value_region"] = {k: in_region[k] for k in ("achieved", "frac", "avg_launch_ms", "launches_per_step", "note")}
         del model_iso
         torch.cuda.empty_cache()
-    if rank == 0 and not a.no_second_mode:
+    if not a.no_second_mode:                     # every rank: run() is collective
         other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         del model
         torch.cuda.empty_cache()
-    if not a.no_second_mode:
-        other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         model2 = make_model(other)
         dt2, q2, _ = run(model2, a.steps, a.warmup)
         out["other_mode"] = {"numerics": other, "value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
