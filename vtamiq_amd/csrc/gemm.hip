@@ -80,95 +80,126 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             if constexpr (EPI == EPI_RESID) g4[nh][ni] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
         }
 
+    // The staged forms work in CHUNKS through two LDS images (above the first K-tile buffer, see STG below): in every barrier
+    // interval the workgroup copies chunk k-1 out to global memory (ds_read_b128 -> 16-byte row-segment stores) and converts
+    // chunk k into the other image, so the stores' address-path time hides behind the next chunk's VALU / LDS writes.
+    constexpr int STG = 65536;                          // staging base: the ring's second K-tile buffer and the slack above it
+    auto interval_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        // chunk (mh, q): the 64 rows {mh*128 + wr*64 + (2q + e)*16 + fr}, image row = wr*32 + e*16 + fr; one pass per plane
         constexpr int RS = 528;                         // 256 bf16 + 16 B pad: rows stay 16-B aligned for ds_read_b128
+        constexpr int IMG = 64 * RS;
         constexpr int NP = (NSPLIT == 1) ? 1 : 2;
-        bf16x4 lo[(NSPLIT == 1) ? 1 : 32];
-        // pass 0: bias (+GELU), hi plane to LDS (lo kept in registers); pass 1: lo plane
+        constexpr int NPASS = MH * 2 * NP;
+        bf16x4 lo[(NSPLIT == 1) ? 1 : 8];               // lo plane of the chunk in flight (written by the next pass)
+        auto convert = [&](int pass) {                  // pass = (mh*2 + q)*NP + pl; all indices fold after unrolling
+            const int pl = pass % NP, cq = pass / NP, mh = cq >> 1, q = cq & 1;
+            char* img = smem + STG + (pass & 1) * IMG;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-            for (int mh = 0; mh < MH; ++mh)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int row = mh * 128 + wr * 64 + mi * 16 + fr;
-                            const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
-                            const int li = ((mh * 4 + mi) * 2 + nh) * 2 + ni;
-                            bf16x4 h;
-                            if (pl == 0) {
-                                const f32x4 a = acc[mh][nh][mi][ni];
-                                const float4 bb = b4[nh][ni];
-                                float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
-                                if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                                }
-                                if constexpr (NSPLIT == 1) {
-                                    h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                                } else {
-                                    bf16x4 l;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) { bf16 x, y; split2(v[e], x, y); h[e] = x; l[e] = y; }
-                                    lo[li] = l;
-                                }
-                            } else {
-                                h = lo[(NSPLIT == 1) ? 0 : li];
-                            }
-                            *(bf16x4*)(smem + row * RS + col * 2) = h;
-                        }
-            __syncthreads();
-            {
-                const int c16 = tid & 31, r0 = tid >> 5;
-                bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
-#pragma unroll
-                for (int ps = 0; ps < 8 * MH; ++ps) {
-                    const int row = ps * 16 + r0;
-                    const uint4 v = *(const uint4*)(smem + row * RS + c16 * 16);
-                    store_nt16(og + (int64_t)row * p.ldo, v);
-                }
-            }
-            if (pl + 1 < NP) __syncthreads();
-        }
-    } else if constexpr (EPI == EPI_RESID) {
-        constexpr int RS = 1040;                        // 256 fp32 + 16 B pad (odd multiple of 16: conflict-free b128 writes)
-#pragma unroll
-        for (int mh = 0; mh < MH; ++mh) {
-            if (mh) __syncthreads();
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        const int row = wr * 64 + mi * 16 + fr;
+                        const int lrow = wr * 32 + e * 16 + fr;
                         const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
-                        const f32x4 a = acc[mh][nh][mi][ni];
-                        const float4 bb = b4[nh][ni], gg = g4[nh][ni];
-                        const float4 v = {gg.x * (a[0] + bb.x), gg.y * (a[1] + bb.y), gg.z * (a[2] + bb.z), gg.w * (a[3] + bb.w)};
-                        *(float4*)(smem + row * RS + col * 4) = v;
+                        const int li = (e * 2 + nh) * 2 + ni;
+                        bf16x4 h;
+                        if (pl == 0) {
+                            const f32x4 a = acc[mh][nh][2 * q + e][ni];
+                            const float4 bb = b4[nh][ni];
+                            float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
+                            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+                            }
+                            if constexpr (NSPLIT == 1) {
+                                h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            } else {
+                                bf16x4 l;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { bf16 x, y; split2(v[k], x, y); h[k] = x; l[k] = y; }
+                                lo[li] = l;
+                            }
+                        } else {
+                            h = lo[(NSPLIT == 1) ? 0 : li];
+                        }
+                        *(bf16x4*)(img + lrow * RS + col * 2) = h;
                     }
-            __syncthreads();
-            const int c16 = tid & 63, r0 = tid >> 6;
-            float* xg = p.x + (m0 + mh * 128) * p.N + n0 + c16 * 4;
+        };
+        auto copy_out = [&](int pass) {
+            const int pl = pass % NP, cq = pass / NP, mh = cq >> 1, q = cq & 1;
+            const char* img = smem + STG + (pass & 1) * IMG;
+            const int c16 = tid & 31, r0 = tid >> 5;
+            bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
 #pragma unroll
-            for (int ps4 = 0; ps4 < 16; ps4 += 4) {
-                float4 xv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = *(const float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int row = (ps4 + u) * 8 + r0;
-                    const float4 d = *(const float4*)(smem + row * RS + c16 * 16);
-                    xv[u].x += d.x; xv[u].y += d.y; xv[u].z += d.z; xv[u].w += d.w;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *(float4*)(xg + (int64_t)((ps4 + u) * 8 + r0) * p.N) = xv[u];
+            for (int ps = 0; ps < 4; ++ps) {            // image row ps*16 + r0 = (wr = ps>>1, e = ps&1, fr = r0)
+                const int grow = mh * 128 + (ps >> 1) * 64 + (2 * q + (ps & 1)) * 16 + r0;
+                const uint4 v = *(const uint4*)(img + (ps * 16 + r0) * RS + c16 * 16);
+                store_nt16(og + (int64_t)grow * p.ldo, v);
             }
+        };
+        convert(0);
+        interval_end();
+#pragma unroll
+        for (int pass = 1; pass < NPASS; ++pass) {
+            copy_out(pass - 1);
+            convert(pass);
+            interval_end();
         }
+        copy_out(NPASS - 1);
+    } else if constexpr (EPI == EPI_RESID) {
+        // chunk (mh, mi): the 32 rows {mh*128 + wr*64 + mi*16 + fr}, image row = wr*16 + fr, fp32; the residual rows of chunk
+        // k are requested one interval before they are needed
+        constexpr int RS = 1040;                        // 256 fp32 + 16 B pad (odd multiple of 16: conflict-free b128 writes)
+        constexpr int IMG = 32 * RS;
+        constexpr int NCH = MH * 4;
+        const int c16 = tid & 63, r0 = tid >> 6;
+        auto grow_of = [&](int ch, int ps) { return (ch >> 2) * 128 + (ps >> 1) * 64 + (ch & 3) * 16 + (ps & 1) * 8 + r0; };
+        auto convert = [&](int ch) {
+            const int mh = ch >> 2, mi = ch & 3;
+            char* img = smem + STG + (ch & 1) * IMG;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                    const f32x4 a = acc[mh][nh][mi][ni];
+                    const float4 bb = b4[nh][ni], gg = g4[nh][ni];
+                    const float4 v = {gg.x * (a[0] + bb.x), gg.y * (a[1] + bb.y), gg.z * (a[2] + bb.z), gg.w * (a[3] + bb.w)};
+                    *(float4*)(img + (wr * 16 + fr) * RS + col * 4) = v;
+                }
+        };
+        float* xg = p.x + m0 * p.N + n0 + c16 * 4;
+        float4 xv[2][4];
+        auto load_x = [&](int ch) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) xv[ch & 1][ps] = *(const float4*)(xg + (int64_t)grow_of(ch, ps) * p.N);
+        };
+        auto copy_out = [&](int ch) {
+            const char* img = smem + STG + (ch & 1) * IMG;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {            // image row ps*8 + r0 = (wr = ps>>1, fr = (ps&1)*8 + r0)
+                const float4 d = *(const float4*)(img + (ps * 8 + r0) * RS + c16 * 16);
+                float4 x = xv[ch & 1][ps];
+                x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+                *(float4*)(xg + (int64_t)grow_of(ch, ps) * p.N) = x;
+            }
+        };
+        load_x(0);
+        convert(0);
+        interval_end();
+#pragma unroll
+        for (int ch = 1; ch < NCH; ++ch) {
+            load_x(ch);
+            copy_out(ch - 1);
+            convert(ch);
+            interval_end();
+        }
+        copy_out(NCH - 1);
     } else {  // EPI_EMBED: scattered rows + table gathers, once per forward: direct from registers
 #pragma unroll
         for (int mh = 0; mh < MH; ++mh)
@@ -432,7 +463,7 @@ double greedy_makespan(int n_full, int n_half) {
 }
 
 // sequence of one XCD owning tiles [t0, t0 + cnt): whole tiles, then `tail` tiles as top/bottom halves
-void xcd_sequence(int t0, int cnt, std::vector<int>& out) {
+void xcd_sequence(const int* order, int cnt, std::vector<int>& out) {
     static const bool all_halves = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return v && v[0] == '2'; }();   // measurement knob
     int best_tail = 0;
     double best = 1e30;
@@ -441,17 +472,21 @@ void xcd_sequence(int t0, int cnt, std::vector<int>& out) {
         if (m < best) { best = m; best_tail = tail; }
     }
     if (all_halves) best_tail = cnt;
-    for (int i = 0; i < cnt - best_tail; ++i) out.push_back((t0 + i) << 2);
-    for (int i = cnt - best_tail; i < cnt; ++i) { out.push_back(((t0 + i) << 2) | 1); out.push_back(((t0 + i) << 2) | 2); }
+    for (int i = 0; i < cnt - best_tail; ++i) out.push_back(order[i] << 2);
+    for (int i = cnt - best_tail; i < cnt; ++i) { out.push_back((order[i] << 2) | 1); out.push_back((order[i] << 2) | 2); }
 }
 
 std::vector<int> build_schedule(int ntm, int ntn) {
     const int nt = ntm * ntn, q = nt / kXcds, r = nt % kXcds;
+    // tile order the XCD runs are cut from: row-major, i.e. the column tiles of one A row panel are neighbours.  (Cutting the
+    // runs from column BANDS of 3 / 4 / 6 tiles instead -- fewer distinct W tiles per XCD round -- measured no different.)
+    std::vector<int> order(nt);
+    for (int i = 0; i < nt; ++i) order[i] = i;
     std::vector<std::vector<int>> seq(kXcds);
     size_t total = 0;
     for (int x = 0; x < kXcds; ++x) {
         const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-        xcd_sequence(t0, q + (x < r ? 1 : 0), seq[x]);
+        xcd_sequence(order.data() + t0, q + (x < r ? 1 : 0), seq[x]);
         total += seq[x].size();
     }
     std::vector<int> out;
