@@ -51,3 +51,25 @@ def rel_err(q, q_ref):
     rms = float(np.sqrt(np.mean(q_ref ** 2)))
     return dict(max_rel=float(np.max(d / np.abs(q_ref))), med_rel=float(np.median(d / np.abs(q_ref))),
                 max_abs=float(d.max()), max_rel_rms=float(d.max() / rms), rms=rms)
+
+
+def stress_state(spec, seed, qk=3.0, mlp=3.0, outlier=8.0):
+    """Seeded weights with trained-ViT-like statistics instead of the flat random init: query/key scaled so the softmax is
+    peaked (mean max-probability 0.5 .. 0.95 instead of 1/S), larger value / MLP gains, and four 'massive activation' channels
+    per layer (LayerNorm gains x8, fc2 bias +2) so the residual stream carries outliers of ~30x its rms."""
+    from vtamiq_amd import synth
+    sd = synth.make_state_dict(spec, seed)
+    rs = np.random.default_rng(seed)
+    for i in range(spec.num_layers):
+        p = f"transformer.encoder.layers.{i}."
+        sd[p + "attn.query.weight"] *= qk
+        sd[p + "attn.key.weight"] *= qk
+        sd[p + "attn.value.weight"] *= 3.0
+        sd[p + "attn.out.weight"] *= 2.0
+        sd[p + "ffn.fc1.weight"] *= mlp
+        sd[p + "ffn.fc2.weight"] *= mlp
+        ch = rs.choice(spec.hidden_size, 4, replace=False)
+        sd[p + "attention_norm.weight"][ch] *= outlier
+        sd[p + "ffn_norm.weight"][ch] *= outlier
+        sd[p + "ffn.fc2.bias"][ch] += 2.0
+    return sd

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, load_case, rel_err, split_inputs
+from tests.helpers import E2E_CASES, load_case, rel_err, split_inputs, stress_state
 from vtamiq_amd import VTAMIQ, synth
 from vtamiq_amd.predict import get_data_tuple, predict
 
@@ -234,3 +234,33 @@ def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, parts, monke
     q_ref = O.vtamiq_forward(O.to_torch(sd), m.spec, cp, cps, cs)[0].numpy()
     assert q.shape == (B,) and np.isfinite(q).all()
     assert gate(q, q_ref, 1e-3), rel_err(q, q_ref)
+
+
+@pytest.mark.parametrize("qk", [3.0, 5.0, 8.0])
+def test_trained_like_statistics_against_oracle(qk):
+    """The flat random init makes attention uniform and activations small, which flatters reduced-precision operands.  Same
+    topology (ViT-B/16, all 12 layers) with peaked softmax rows (mean max-probability ~0.6 / ~0.85 / ~0.95) and outlier channels
+    of ~30x the stream's rms.  Near one-hot attention makes the MODEL ill-conditioned: the oracle itself moves by `cond` between
+    fp32 and fp64 arithmetic (5e-6 / 2.5e-4 / 5e-4 here), i.e. it amplifies a 6e-8 rounding by up to 1e4.  bf16x3 operands
+    carry 2^-17, so the bound that can be asked of it is max(1e-3, 30 * cond): the north-star 1e-3 wherever the fp32 reference
+    is itself reproducible to ~3e-5, proportionally more where it is not.  The single-MFMA mode's error is printed."""
+    kw = dict(vit_config=dict(variant="ViT-B16"))
+    spec = VTAMIQ(**json.loads(json.dumps(kw))).spec
+    sd = stress_state(spec, 5, qk=qk)
+    patches, pos, sc = synth.make_inputs(spec, 3, 90, 9)
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    cp, cps, cs = split_inputs(patches, pos, sc)
+    q_ref = O.vtamiq_forward(O.to_torch(sd), spec, cp, cps, cs)[0].numpy()
+    q_f64 = O.vtamiq_forward(O.to_torch(sd, dtype=torch.float64), spec, [t.double() for t in cp], [t.double() for t in cps], cs)[0].numpy()
+    cond = rel_err(q_ref, q_f64)["max_rel_rms"]
+    tol = max(1e-3, 30.0 * cond)
+    errs = {}
+    for precision in ("bf16x3", "bf16"):
+        m = build(kw, sd, precision)
+        with torch.no_grad():
+            q = m(p, ps, s3)[0].cpu().numpy()
+        assert np.isfinite(q).all()
+        errs[precision] = rel_err(q, q_ref)["max_rel_rms"]
+        if precision == "bf16x3":
+            assert gate(q, q_ref, tol), (q, q_ref, errs, cond)
+    print("trained-like statistics qk=%g: oracle fp32-vs-fp64 %.1e, tolerance %.1e, errors %s" % (qk, cond, tol, errs))
