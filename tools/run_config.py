@@ -10,8 +10,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--variant", default="ViT-L16"); ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--patches", type=int, default=1024); ap.add_argument("--scales", type=int, default=3)
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--refdefault", action="store_true", help="the reference's default topology (train_config.py:169-194): 6 layers, 8 register tokens, LayerScale, r = 16")
 a = ap.parse_args()
 kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales))
+if a.refdefault:
+    kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales), ca_reduction=16)
 for prec in ("bf16x3", "bf16"):
     m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
     spec = m.spec
