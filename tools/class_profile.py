@@ -8,10 +8,12 @@ from vtamiq_amd import VTAMIQ, synth, _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--patches", type=int, default=500)
+ap.add_argument("--refdefault", action="store_true")
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["bf16x3", "bf16"])
 a = ap.parse_args()
 for prec in a.precision:
-    m = VTAMIQ(precision=prec)
+    m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True),
+                                       ca_reduction=16) if a.refdefault else {}))
     sd = synth.make_state_dict(m.spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
     patches, pos, _ = synth.make_inputs(m.spec, a.batch, a.patches, 7)
