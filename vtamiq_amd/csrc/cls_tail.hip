@@ -92,11 +92,15 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restric
 }
 
 // attention of the single CLS query of each (sequence, head) over the S keys of the sequence; K, V from the packed bf16 planes.
+// One 4-wave workgroup per (sequence, head): thread t scores keys t, t+256, ...; wave w accumulates the keys = w (mod 4)
+// of the PV sum, four keys in flight per iteration; partial maxima / sums / outputs meet in LDS.
 template <int NPL>
-__global__ __launch_bounds__(64) void cls_attention_kernel(const float* __restrict__ q, const bf16* __restrict__ qkv, int64_t plane,
-                                                           float* __restrict__ out, int S, int S_pad, int H) {
+__global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ q, const bf16* __restrict__ qkv, int64_t plane,
+                                                            float* __restrict__ out, int S, int S_pad, int H) {
     __shared__ float ps[2048];
-    const int lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, seq = blockIdx.y;
     const int ld = 3 * H;
     const bf16* kb = qkv + ((int64_t)seq * S_pad) * ld + H + head * 64;
@@ -107,18 +111,19 @@ __global__ __launch_bounds__(64) void cls_attention_kernel(const float* __restri
         const float4 t = ((const float4*)(q + (int64_t)seq * H + head * 64))[i];
         qv[4 * i] = t.x; qv[4 * i + 1] = t.y; qv[4 * i + 2] = t.z; qv[4 * i + 3] = t.w;
     }
-    // scores: lane owns keys lane, lane+64, ...
     float mx = -INFINITY;
-    for (int key = lane; key < S; key += 64) {
+    for (int key = tid; key < S; key += 256) {
         const bf16* kr = kb + (int64_t)key * ld;
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const bf16x8 kh = ((const bf16x8*)kr)[c];
+            bf16x8 kl;
+            if constexpr (NPL == 2) kl = ((const bf16x8*)(kr + plane))[c];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float kv = (float)kh[e];
-                if constexpr (NPL == 2) kv += (float)((const bf16*)(kr + plane))[c * 8 + e];
+                if constexpr (NPL == 2) kv += (float)kl[e];
                 s += qv[c * 8 + e] * kv;
             }
         }
@@ -128,22 +133,35 @@ __global__ __launch_bounds__(64) void cls_attention_kernel(const float* __restri
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int key = lane; key < S; key += 64) {
+    for (int key = tid; key < S; key += 256) {
         const float p = expf(ps[key] - mx);
         ps[key] = p;
         sum += p;
     }
     sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    // out[d = lane] = sum_key p[key] * V[key][d]
-    float o = 0.f;
-    for (int key = 0; key < S; ++key) {
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    // out[d = lane] = sum_key p[key] * V[key][d]; wave w takes keys w, w+4, ...
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    auto vat = [&](int key) {
         float vv = (float)vb[(int64_t)key * ld + lane];
         if constexpr (NPL == 2) vv += (float)vb[(int64_t)key * ld + plane + lane];
-        o += ps[key] * vv;
+        return vv;
+    };
+    int key = wave;
+    for (; key + 12 < S; key += 16) {
+        const float v0 = vat(key), v1 = vat(key + 4), v2 = vat(key + 8), v3 = vat(key + 12);
+        o0 += ps[key] * v0; o1 += ps[key + 4] * v1; o2 += ps[key + 8] * v2; o3 += ps[key + 12] * v3;
     }
-    out[(int64_t)seq * H + head * 64 + lane] = o / sum;
+    for (; key < S; key += 4) o0 += ps[key] * vat(key);
+    part[wave][lane] = (o0 + o1) + (o2 + o3);
+    __syncthreads();
+    if (wave == 0) out[(int64_t)seq * H + head * 64 + lane] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / sum;
 }
 
 }  // namespace
@@ -171,7 +189,7 @@ hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, in
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
                                 int nsplit, hipStream_t s) {
     if (S > 2048) return hipErrorInvalidValue;
-    const dim3 g(H / 64, nseq), blk(64);
+    const dim3 g(H / 64, nseq), blk(256);
     if (nsplit == 1) hipLaunchKernelGGL(cls_attention_kernel<1>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
     else hipLaunchKernelGGL(cls_attention_kernel<2>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
     return hipGetLastError();
