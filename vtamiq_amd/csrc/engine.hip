@@ -203,7 +203,7 @@ struct Geometry {
 Geometry geometry(const vtq_engine* e, int B, int N, int nimg = 2) {
     Geometry g;
     g.S = N + e->T;
-    g.S_pad = (int)round_up(g.S, 64);
+    g.S_pad = (int)round_up(g.S, 32);          // sequences are S_pad rows apart; attention's last 64-key tile may run 32 rows into the next one (masked)
     g.nseq = nimg * B;
     g.M_pad = round_up((int64_t)g.nseq * g.S_pad, 256);
     g.P_pad = round_up((int64_t)nimg * B * N, 256);
