@@ -112,9 +112,12 @@ def _attention_ref(qkv, nseq, S, S_pad, H):
 @pytest.mark.parametrize("nsplit", [1, 3])
 @pytest.mark.parametrize("nseq,S,H", [(4, 501, 768), (3, 51, 768), (2, 1025, 1024), (2, 64, 768), (2, 509, 768), (5, 521, 768), (3, 9, 768),
                                       (2, 96, 768)])
-def test_attention(nsplit, nseq, S, H):
+@pytest.mark.parametrize("packed", [True, False])
+def test_attention(nsplit, nseq, S, H, packed):
     lib = _lib.load()
-    S_pad = (S + 31) // 32 * 32          # the engine's sequence pitch: 521 -> 544, 1025 -> 1056, 9 -> 32 (half a key tile)
+    # sequence pitch: the engine packs sequences back to back (pitch = S: the last key tile / query block of a sequence runs
+    # into the next one and is masked / not stored); a padded pitch must work as well
+    S_pad = S if packed else (S + 31) // 32 * 32
     rows = nseq * S_pad + 128
     qkv = _randn(rows, 3 * H, seed=16, scale=1.5)
     # a spike so that the running max moves late in the sequence (online-softmax rescale path)

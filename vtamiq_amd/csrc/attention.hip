@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
     // NSTAGE-deep K/V ring: tile t+NSTAGE-1 is in flight while tile t is consumed (counted vmcnt, one barrier per tile)
     constexpr int DMA_PER_TILE = 2 * KB * NPL;
-    const int nt = (S_pad + KT - 1) / KT;      // S_pad % 64 == 32: the last tile's upper half are the next sequence's rows, keys >= S are masked
+    const int nt = (S + KT - 1) / KT;          // the last tile may run into the next sequence's rows: keys >= S are masked
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
         if (t < nt) stage(t, t);
@@ -279,7 +279,7 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s) {
-    if (H % 64 || S_pad % 32 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
+    if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
     const char* st = getenv("VTQ_ATTN_VARIANT");      // experiments: "s<stages>k<keys>" e.g. s2k32
     const int v = st ? atoi(st) : 0;
     if (nsplit == 1) {

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg
 // UvPosEmbedding.forward index (transformer.py:417-421): floor(pos*G) -> i0*G + i1 + 1, evaluated in fp32 like torch;
 // ScaleEmbedding.forward index (transformer.py:396-398): clamp(scale, 0, num_scales-1) + 1.
 __global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __restrict__ pidx, int* __restrict__ sidx,
-                                   int* __restrict__ row_map, int B, int N, int rows_pad, int S_pad, int T, int grid, int num_scales) {
+                                   int* __restrict__ row_map, int B, int N, int rows_pad, SeqMap sm, int T, int grid, int num_scales) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows_pad) return;
     const int BN = B * N;
@@ -75,32 +75,36 @@ __global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __res
     }
     sidx[r] = si;
     const int b = rr / N, n = rr - b * N;
-    row_map[r] = (img * B + b) * S_pad + T + n;
+    row_map[r] = (int)seq_row(sm, img * B + b) + T + n;
 }
 
 // Embeddings.forward_tokens (transformer.py:507-524): row 0 = cls + pos_table[0]; rows 1..T-1 = register tokens.
 __global__ void tokens_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos_table,
-                              const float* __restrict__ extra, int S_pad, int T, int H) {
+                              const float* __restrict__ extra, SeqMap sm, int T, int H) {
     const int seq = blockIdx.x, t = blockIdx.y;
-    float* dst = x + ((int64_t)seq * S_pad + t) * H;
+    float* dst = x + (seq_row(sm, seq) + t) * H;
     for (int c = threadIdx.x; c < H; c += blockDim.x) dst[c] = (t == 0) ? cls[c] + pos_table[c] : extra[(t - 1) * H + c];
 }
 
-__global__ void zero_pad_rows_kernel(float* __restrict__ x, int nseq, int S, int S_pad, int H4, int rows_total) {
-    const int per_seq = S_pad - S;
-    const int npad = nseq * per_seq + (rows_total - nseq * S_pad);
+__global__ void zero_pad_rows_kernel(float* __restrict__ x, int nseq, int S, SeqMap sm, int H4, int rows_total) {
+    const int per_seq = sm.pitch - S;                                   // pad rows behind every sequence
+    const int nparts = (nseq + sm.per - 1) / sm.per;
+    const int64_t part_rows = (int64_t)sm.per * sm.pitch + sm.gap;
+    const int n_seq = nseq * per_seq, n_gap = nparts * sm.gap;
+    const int npad = n_seq + n_gap + (int)(rows_total - nparts * part_rows);
     for (int i = blockIdx.x; i < npad; i += gridDim.x) {
         int64_t row;
-        if (i < nseq * per_seq) { const int sq = i / per_seq; row = (int64_t)sq * S_pad + S + (i - sq * per_seq); }
-        else row = (int64_t)nseq * S_pad + (i - nseq * per_seq);
+        if (i < n_seq) { const int sq = i / per_seq; row = seq_row(sm, sq) + S + (i - sq * per_seq); }
+        else if (i < n_seq + n_gap) { const int j = i - n_seq, pt = j / sm.gap; row = pt * part_rows + (int64_t)sm.per * sm.pitch + (j - pt * sm.gap); }
+        else row = nparts * part_rows + (i - n_seq - n_gap);
         float4* d = (float4*)x + row * H4;
         for (int c = threadIdx.x; c < H4; c += blockDim.x) d[c] = float4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-__global__ void copy_tokens_kernel(const float* __restrict__ x, float* __restrict__ dst, int S_pad, int T, int H) {
+__global__ void copy_tokens_kernel(const float* __restrict__ x, float* __restrict__ dst, SeqMap sm, int T, int H) {
     const int seq = blockIdx.x, t = blockIdx.y;
-    const float* src = x + ((int64_t)seq * S_pad + t) * H;
+    const float* src = x + (seq_row(sm, seq) + t) * H;
     float* d = dst + ((int64_t)seq * T + t) * H;
     for (int c = threadIdx.x; c < H; c += blockDim.x) d[c] = src[c];
 }
@@ -157,13 +161,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int V4>
 __global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ gamma,
-                                                        float* __restrict__ d, int B, int S_pad) {
+                                                        float* __restrict__ d, int B, SeqMap sm) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x;
     const int pb = blockIdx.x, j = blockIdx.y;           // j-th distorted image (0 for FR pairs; 0,1 for pairwise triplets)
     float4 yr[V4], yd[V4];
-    ln_row<V4>(x + (int64_t)pb * S_pad * H, w, b, lane, yr);
-    ln_row<V4>(x + (int64_t)((j + 1) * B + pb) * S_pad * H, w, b, lane, yd);
+    ln_row<V4>(x + seq_row(sm, pb) * H, w, b, lane, yr);
+    ln_row<V4>(x + seq_row(sm, (j + 1) * B + pb) * H, w, b, lane, yd);
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
         float4 r = {yr[i].x - yd[i].x, yr[i].y - yd[i].y, yr[i].z - yd[i].z, yr[i].w - yd[i].w};
@@ -203,29 +207,30 @@ hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, in
 }
 
 hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
-                              int rows_pad, int S_pad, int T, int grid, int num_scales, hipStream_t s) {
+                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, hipStream_t s) {
     ImgPtrs pp{{pos[0], pos[1], nimg > 2 ? pos[2] : nullptr}};
     ImgPtrs sp{{sc ? sc[0] : nullptr, sc ? sc[1] : nullptr, (sc && nimg > 2) ? sc[2] : nullptr}};
     hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pp, sp, nimg, pidx, sidx, row_map, B, N, rows_pad,
-                       S_pad, T, grid, num_scales);
+                       sm, T, grid, num_scales);
     return hipGetLastError();
 }
 
-hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, int S_pad, int T,
+hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, SeqMap sm, int T,
                          int H, hipStream_t s) {
-    hipLaunchKernelGGL(tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, cls, pos_table, extra, S_pad, T, H);
+    hipLaunchKernelGGL(tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, cls, pos_table, extra, sm, T, H);
     return hipGetLastError();
 }
 
-hipError_t launch_zero_pad_rows(float* x, int nseq, int S, int S_pad, int H, int rows_total, hipStream_t s) {
-    const int npad = nseq * (S_pad - S) + (rows_total - nseq * S_pad);
+hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s) {
+    const int nparts = (nseq + sm.per - 1) / sm.per;
+    const int64_t npad = (int64_t)nseq * (sm.pitch - S) + (int64_t)nparts * sm.gap + (rows_total - nparts * ((int64_t)sm.per * sm.pitch + sm.gap));
     if (npad <= 0) return hipSuccess;
-    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(npad < 4096 ? npad : 4096), dim3(256), 0, s, x, nseq, S, S_pad, H / 4, rows_total);
+    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(npad < 4096 ? (int)npad : 4096), dim3(256), 0, s, x, nseq, S, sm, H / 4, rows_total);
     return hipGetLastError();
 }
 
-hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, int S_pad, int T, int H, hipStream_t s) {
-    hipLaunchKernelGGL(copy_tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, dst, S_pad, T, H);
+hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, int T, int H, hipStream_t s) {
+    hipLaunchKernelGGL(copy_tokens_kernel, dim3(nseq, T), dim3(256), 0, s, x, dst, sm, T, H);
     return hipGetLastError();
 }
 
@@ -243,9 +248,9 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, void
 }
 
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
-                             int S_pad, int H, hipStream_t s) {
-    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
-    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, S_pad);
+                             SeqMap sm, int H, hipStream_t s) {
+    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm);
+    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

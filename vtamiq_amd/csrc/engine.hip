@@ -195,30 +195,49 @@ int build(vtq_engine* e) {
 }
 
 struct Geometry {
-    int S, S_pad, nseq;
+    int S, S_pad, nseq;          // S_pad: row pitch of a sequence (= S: sequences are packed back to back)
+    int nparts, per;             // part-batches (separate streams) and sequences per part
+    int64_t part_rows;           // rows of one part-batch, a multiple of 256 (the GEMM tile height)
     int64_t M_pad, P_pad, rows_alloc;
+    SeqMap sm;
 };
 
 // nimg images per item: 2 = (ref, dist) FR pair, 3 = (ref, dist1, dist2) pairwise triplet
 Geometry geometry(const vtq_engine* e, int B, int N, int nimg = 2) {
     Geometry g;
     g.S = N + e->T;
-    g.S_pad = (int)round_up(g.S, 32);          // sequences are S_pad rows apart; attention's last 64-key tile may run 32 rows into the next one (masked)
+    // No per-sequence padding: attention masks keys >= S (its last 64-key tile and last 128-query block run into the next
+    // sequence's rows, or into the part's tail / the 128 slack rows: finite values, never stored), every other kernel is
+    // row-independent.  Only a part-batch is padded, to the GEMM tile height.
+    g.S_pad = g.S;
     g.nseq = nimg * B;
-    g.M_pad = round_up((int64_t)g.nseq * g.S_pad, 256);
+    g.nparts = e->nparts;
+    while (g.nparts > 1 && g.nseq % g.nparts) g.nparts >>= 1;
+    if (e->cfg.num_layers < 2) g.nparts = 1;
+    g.per = g.nseq / g.nparts;
+    g.part_rows = round_up((int64_t)g.per * g.S_pad, 256);
+    g.M_pad = g.nparts * g.part_rows;
     g.P_pad = round_up((int64_t)nimg * B * N, 256);
-    g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention query over-read slack
+    g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention over-read slack behind the last part
+    g.sm = SeqMap{g.S_pad, g.per, (int)(g.part_rows - (int64_t)g.per * g.S_pad)};
     return g;
 }
 
+// capacity for up to `B` sequence pairs however a call partitions them (<= 4 parts, each padded to 256 rows)
+int64_t capacity_rows(const vtq_engine* e, int B, int N) {
+    const int64_t seq_rows = round_up((int64_t)2 * B * (N + e->T), 256) + 4 * 256;
+    const int64_t patch_rows = round_up((int64_t)2 * B * N, 256);
+    return (seq_rows > patch_rows ? seq_rows : patch_rows) + 128;
+}
+
 size_t workspace_bytes(const vtq_engine* e, int B, int N) {
-    const Geometry g = geometry(e, B, N);
+    const int64_t rows = capacity_rows(e, B, N), P_pad = round_up((int64_t)2 * B * N, 256);
     const int64_t H = e->H, Wmax = (3 * H > e->Mdim ? 3 * H : e->Mdim);
     size_t b = 0;
-    b += (size_t)g.rows_alloc * H * 4;                    // residual stream fp32
-    b += (size_t)g.rows_alloc * H * 2 * e->npl;           // LN / attention output planes
-    b += (size_t)g.rows_alloc * Wmax * 2 * e->npl;        // qkv | mlp hidden | packed patches planes
-    b += (size_t)g.P_pad * 4 * 3;                         // pos/scale indices, row map
+    b += (size_t)rows * H * 4;                            // residual stream fp32
+    b += (size_t)rows * H * 2 * e->npl;                   // LN / attention output planes
+    b += (size_t)rows * Wmax * 2 * e->npl;                // qkv | mlp hidden | packed patches planes
+    b += (size_t)P_pad * 4 * 3;                           // pos/scale indices, row map
     b += (size_t)2 * B * H * 4 * 6;                       // head ping-pong buffers (pairwise: 2 scores per item)
     b += (size_t)2 * B * (4 * H + e->Mdim) * 4;           // CLS-only last-layer rows
     return b;
@@ -231,7 +250,7 @@ int reserve(vtq_engine* e, int B, int N) {
     for (void* p : e->ws_allocs) (void)hipFree(p);
     e->ws_allocs.clear();
     e->x = nullptr;
-    const Geometry g = geometry(e, nB, nN);
+    struct { int64_t rows_alloc, P_pad; } g{capacity_rows(e, nB, nN), round_up((int64_t)2 * nB * nN, 256)};
     const int64_t H = e->H, Wmax = (3 * H > e->Mdim ? 3 * H : e->Mdim);
     e->rows_alloc = g.rows_alloc;
     e->ln_plane = g.rows_alloc * H;
@@ -284,7 +303,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, in
     const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit, L = c.num_layers;
     hipStream_t s = pt.s;
     const int M = (int)pt.rows;
-    const int64_t row0 = (int64_t)pt.seq0 * g.S_pad;
+    const int64_t row0 = (int64_t)(pt.seq0 / g.per) * g.part_rows;     // parts start at multiples of part_rows
     const int64_t Wmax = (3 * H > Md ? 3 * H : Md);
     float* x = e->x + row0 * H;
     char* lnb = (char*)e->lnbuf + row0 * H * 2;
@@ -359,7 +378,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, in
             a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = x;
             HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
         }
-        if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride + (int64_t)pt.seq0 * T * H, pt.nseq, g.S_pad, T, H, s));
+        if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride + (int64_t)pt.seq0 * T * H, pt.nseq, SeqMap{g.S_pad, pt.nseq, 0}, T, H, s));
     }
     return 0;
 }
@@ -494,16 +513,15 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(e, B, N, nimg);
     const int H = e->H, T = e->T, ns = e->nsplit;
-    const int L = c.num_layers;
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
         HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, ns, s));
-        HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.S_pad, T,
+        HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
                                    c.pos_grid, c.num_scales, s));
-        HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.S_pad, H, (int)e->rows_alloc, s));
-        HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.S_pad, T, H, s));
+        HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
+        HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.sm, T, H, s));
     }
     {
         Prof p(e, s, VTQ_K_PATCH);
@@ -516,22 +534,19 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
         HIP_TRY(launch_gemm(a, ns, EPI_EMBED, s));
     }
-    if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.S_pad, T, H, s));
+    if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
 
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
     const bool prune = e->cls_prune && !e->trace;      // the trace tap needs every token row of the last layer
     // Part-batches on separate streams: the dispatcher then always has ready workgroups of a DIFFERENT kernel to fill
     // partially occupied rounds (N = 768 GEMMs are 1.5 rounds at B = 32), and one part's store bursts / LayerNorm overlap
     // another part's MFMA loops.  Parts are contiguous sequence ranges (ref images first), all kernels are row-independent.
-    int nparts = e->nparts;
-    while (nparts > 1 && (g.nseq % nparts || ((int64_t)(g.nseq / nparts) * g.S_pad) % 256)) nparts >>= 1;
-    if (nparts > 1 && L > 1) {
-        const int per = g.nseq / nparts;
+    if (g.nparts > 1) {
         HIP_TRY(hipEventRecord(e->ev_fork, s));
-        for (int pi = 0; pi < nparts; ++pi) {
+        for (int pi = 0; pi < g.nparts; ++pi) {
             hipStream_t ps = pi == 0 ? s : e->side[pi - 1];
             if (pi) HIP_TRY(hipStreamWaitEvent(ps, e->ev_fork, 0));
-            Part pt{pi * per, per, (int64_t)per * g.S_pad, ps};
+            Part pt{pi * g.per, g.per, g.part_rows, ps};
             if (run_encoder(e, g, pt, prune, 0, nullptr)) return 1;
             if (pi) {
                 HIP_TRY(hipEventRecord(e->ev_join[pi - 1], ps));
@@ -547,8 +562,8 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     {
         Prof p(e, s, VTQ_K_HEAD);
         float* d = e->hb[0];
-        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, 1, H, s));
-        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.S_pad, H, s));
+        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, s));
+        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, s));
         if (c.calibrate) {
             float* xr = e->hb[0];       // residual-group input
             float* xr_next = e->hb[1];

@@ -9,6 +9,11 @@ namespace vtq {
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
 
+// Where the sequences live in the row-major activation buffers: sequence s starts at row s*pitch + (s/per)*gap -- `per`
+// sequences per part-batch, each part-batch padded by `gap` rows to a multiple of 256 (the GEMM tile height).
+struct SeqMap { int pitch, per, gap; };
+__host__ __device__ inline int64_t seq_row(const SeqMap& m, int s) { return (int64_t)s * m.pitch + (int64_t)(s / m.per) * m.gap; }
+
 struct GemmArgs {
     const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
     const void* W; int64_t w_plane;               // bf16 planes [N, K]
@@ -35,10 +40,10 @@ hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, in
 
 // per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1)
 hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
-                              int rows_pad, int S_pad, int T, int grid, int num_scales, hipStream_t s);
+                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, hipStream_t s);
 
-// CLS (+pos row 0) and register tokens into rows [seq*S_pad, seq*S_pad + T)
-hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, int S_pad,
+// CLS (+pos row 0) and register tokens into the first T rows of every sequence
+hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, SeqMap sm,
                          int T, int H, hipStream_t s);
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
@@ -47,15 +52,15 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, void
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s);
 
-// zero the padding rows of the residual stream: [seq*S_pad + S, (seq+1)*S_pad) for every sequence and [nseq*S_pad, rows_total)
-hipError_t launch_zero_pad_rows(float* x, int nseq, int S, int S_pad, int H, int rows_total, hipStream_t s);
+// zero the rows of the residual stream that belong to no token: per-sequence pads, per-part tails, and everything up to rows_total
+hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s);
 
 // copy token rows (first T rows of each sequence) of x into trace[nseq][T][H]
-hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, int S_pad, int T, int H, hipStream_t s);
+hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, int T, int H, hipStream_t s);
 
 // d[j*B + b] = gamma * (LN(x[row(b)]) - LN(x[row((j+1)*B + b)])), j < ndist  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
-                             int S_pad, int H, hipStream_t s);
+                             SeqMap sm, int H, hipStream_t s);
 
 // y[b][n] = post( sum_k W[n][k] * pre(x[b][k]) + bias[n] ) (+ res[b][n]);  pre/post: optional PReLU(slope ptr)
 hipError_t launch_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope,
