@@ -16,10 +16,6 @@
 //   * NSPLIT == 3: Q,K,V,P are hi/lo bf16 pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
 #include <cstdlib>
 
-#ifndef VTQ_ATT_ABL
-#define VTQ_ATT_ABL 0      // diagnostic ablations (build with -DVTQ_ATT_ABL=n): 1 no exp, 2 no hi/lo correction MFMAs, 4 no P split
-#endif
-
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 const int off = kb * 32 * 128 + k_rd + (((2 * tt + hh) ^ k_sw) << 4);
                 const bf16x8 kf = *(const bf16x8*)(sk + off);
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], tt == 0 ? zero16 : sacc[kb], 0, 0, 0);
-                if constexpr (NSPLIT == 3 && !(VTQ_ATT_ABL & 2)) {
+                if constexpr (NSPLIT == 3) {
                     const bf16x8 kl = *(const bf16x8*)(sk + TB + off);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][tt], sacc[kb], 0, 0, 0);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][tt], sacc[kb], 0, 0, 0);
@@ -168,11 +164,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#if (VTQ_ATT_ABL & 1)
-                const float pv = fmaf(sacc[kb][r], sc, nm);
-#else
                 const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
-#endif
                 sacc[kb][r] = pv;
                 rs += pv;
             }
@@ -197,11 +189,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 for (int j = 0; j < 8; ++j) {
                     const float pv = sacc[kb][8 * s2 + j];
                     if constexpr (NSPLIT == 1) ph[j] = (bf16)pv;
-#if (VTQ_ATT_ABL & 4)
-                    else { ph[j] = (bf16)pv; pl_[j] = (bf16)pv; }
-#else
                     else { bf16 a, b; split2(pv, a, b); ph[j] = a; pl_[j] = b; }
-#endif
                 }
                 const int vrow = kb * 32 + 16 * s2 + v_row;
 #pragma unroll
@@ -212,7 +200,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     const bf16x4 v1 = lds_tr16(a0 + 8 * 128);
                     const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, o_acc[d], 0, 0, 0);
-                    if constexpr (NSPLIT == 3 && !(VTQ_ATT_ABL & 2)) {
+                    if constexpr (NSPLIT == 3) {
                         const bf16x4 w0 = lds_tr16(a0 + TB);
                         const bf16x4 w1 = lds_tr16(a0 + TB + 8 * 128);
                         const bf16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
@@ -280,15 +268,7 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s) {
     if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-    const char* st = getenv("VTQ_ATTN_VARIANT");      // experiments: "s<stages>k<keys>" e.g. s2k32
-    const int v = st ? atoi(st) : 0;
-    if (nsplit == 1) {
-        if (v == 232) return launch_attention_t<1, 2, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-        if (v == 364) return launch_attention_t<1, 3, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-        return launch_attention_t<1, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-    }
-    if (v == 232) return launch_attention_t<3, 2, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-    if (v == 332) return launch_attention_t<3, 3, 32>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    if (nsplit == 1) return launch_attention_t<1, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
     return launch_attention_t<3, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
 }
 

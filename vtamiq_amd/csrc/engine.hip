@@ -296,9 +296,8 @@ struct Prof {
 
 struct Part { int seq0, nseq; int64_t rows; hipStream_t s; };
 
-// All encoder layers for the sequences [seq0, seq0 + nseq) (rows seq0*S_pad ...), enqueued on pt.s.  `skew_after` > 0:
-// record `skew_ev` after that many kernels of layer 0 (the other half-batch is released there).
-int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, int skew_after, hipEvent_t skew_ev) {
+// All encoder layers for the sequences [seq0, seq0 + nseq) of one part-batch, enqueued on pt.s.
+int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune) {
     const vtq_config& c = e->cfg;
     const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit, L = c.num_layers;
     hipStream_t s = pt.s;
@@ -311,11 +310,6 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, in
     float *xcls = e->xcls + (int64_t)pt.seq0 * H, *lncls = e->lncls + (int64_t)pt.seq0 * H, *qcls = e->qcls + (int64_t)pt.seq0 * H,
           *acls = e->acls + (int64_t)pt.seq0 * H, *h1cls = e->h1cls + (int64_t)pt.seq0 * Md;
     const int64_t trace_stride = (int64_t)g.nseq * T * H;
-    int nk = 0;
-    auto tick = [&]() -> int {
-        if (skew_after > 0 && ++nk == skew_after) HIP_TRY(hipEventRecord(skew_ev, s));
-        return 0;
-    };
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
         if (prune && i == L - 1) {
@@ -355,7 +349,6 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune, in
             HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
         }
         { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, pt.nseq, g.S, g.S_pad, H, ns, s)); }
-        if (i == 0 && tick()) return 1;
         {
             Prof p(e, s, VTQ_K_OUTPROJ);
             GemmArgs a{};
@@ -547,7 +540,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
             hipStream_t ps = pi == 0 ? s : e->side[pi - 1];
             if (pi) HIP_TRY(hipStreamWaitEvent(ps, e->ev_fork, 0));
             Part pt{pi * g.per, g.per, g.part_rows, ps};
-            if (run_encoder(e, g, pt, prune, 0, nullptr)) return 1;
+            if (run_encoder(e, g, pt, prune)) return 1;
             if (pi) {
                 HIP_TRY(hipEventRecord(e->ev_join[pi - 1], ps));
                 HIP_TRY(hipStreamWaitEvent(s, e->ev_join[pi - 1], 0));
@@ -555,7 +548,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         }
     } else {
         Part pa{0, g.nseq, g.M_pad, s};
-        if (run_encoder(e, g, pa, prune, 0, nullptr)) return 1;
+        if (run_encoder(e, g, pa, prune)) return 1;
     }
 
     // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------
