@@ -22,22 +22,15 @@
 namespace vtq {
 namespace {
 
-template <int N> __device__ __forceinline__ void wait_dma_attn() {
-    static_assert(N == 4 || N == 8 || N == 16, "vmcnt immediate");
-    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-}
-
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
-template <int NSPLIT, int NSTAGE, int KT>
+template <int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, int64_t plane, bf16* __restrict__ out,
                                                         int64_t o_plane, int S, int S_pad, int H) {
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
-    constexpr int KB = KT / 32;              // 32-key blocks per K/V tile (KT = 64 | 32 keys)
+    constexpr int KT = 64, KB = KT / 32;     // 64-key K/V tiles = two 32-key blocks; two LDS buffers (3-deep rings and 32-key tiles: no gain)
     constexpr int TB = KT * 128;             // one KT-key x 64-dim bf16 tile
     constexpr int STAGE = TB * NPL * 2;      // K planes then V planes
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,20 +99,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     float m_run = -1e30f, l_run = 0.f;
     const float sc = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
 
-    // NSTAGE-deep K/V ring: tile t+NSTAGE-1 is in flight while tile t is consumed (counted vmcnt, one barrier per tile)
-    constexpr int DMA_PER_TILE = 2 * KB * NPL;
+    // two K/V buffers: tile t+1 is in flight while tile t is consumed, one barrier per tile
     const int nt = (S + KT - 1) / KT;          // the last tile may run into the next sequence's rows: keys >= S are masked
-#pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t)
-        if (t < nt) stage(t, t);
-    if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (nt >= NSTAGE - 1) wait_dma_attn<DMA_PER_TILE*(NSTAGE - 2)>();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-        int nxt = cur + NSTAGE - 1; if (nxt >= NSTAGE) nxt -= NSTAGE;
-        if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, nxt);
+        const int nxt = cur ^ 1;
+        if (t + 1 < nt) stage(t + 1, nxt);
         const char* sk = smem + cur * STAGE;
         const char* sv = sk + NPL * TB;
 
@@ -210,16 +198,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 }
             }
 
-        // tile t+1 must have landed; younger tiles (t+2 .. t+NSTAGE-1) may stay in flight
-        {
-            const int younger = nt - 2 - t < NSTAGE - 2 ? nt - 2 - t : NSTAGE - 2;
-            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (younger >= 2) wait_dma_attn<DMA_PER_TILE * 2>();
-            else if (younger == 1) wait_dma_attn<DMA_PER_TILE>();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 has landed
         __syncthreads();
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        cur = nxt;
     }
 
     // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
@@ -251,25 +232,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
 }  // namespace
 
-template <int NSPLIT, int NSTAGE, int KT>
+template <int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s) {
-    constexpr int LDS = NSTAGE * 2 * KT * 128 * (NSPLIT == 1 ? 1 : 2);
+    constexpr int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<NSPLIT, NSTAGE, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         configured = true;
     }
     const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
-    hipLaunchKernelGGL((attention_kernel<NSPLIT, NSTAGE, KT>), grid, blk, LDS, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S, S_pad, H);
+    hipLaunchKernelGGL((attention_kernel<NSPLIT>), grid, blk, LDS, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S, S_pad, H);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
                             int nsplit, hipStream_t s) {
     if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-    if (nsplit == 1) return launch_attention_t<1, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-    return launch_attention_t<3, 2, 64>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    if (nsplit == 1) return launch_attention_t<1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    return launch_attention_t<3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
 }
 
 }  // namespace vtq
