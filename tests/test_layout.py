@@ -144,3 +144,34 @@ def test_gemm_tile_schedule_covers_every_tile_once():
         bot = np.bincount(tile[kind == 2], minlength=nt)
         assert ((whole == 1) & (top == 0) & (bot == 0) | (whole == 0) & (top == 1) & (bot == 1)).all(), (M, N)
         assert n == nt + int((kind == 1).sum())
+
+
+def test_abi_rejects_bad_arguments_without_touching_a_gpu():
+    """Error behaviour of the C ABI (include/vtamiq_hip.h: non-zero return + vtq_last_error text, no exceptions): argument
+    validation happens before any HIP call, so it is checkable here."""
+    import ctypes as C
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+
+    class Cfg(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("hidden_size", "mlp_dim", "num_heads", "num_layers", "patch_dim", "pos_grid",
+                    "num_extra_tokens", "num_scales", "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs",
+                    "ca_hidden", "precision")] + [("reserved", C.c_int32 * 5)]
+    good = dict(hidden_size=768, mlp_dim=3072, num_heads=12, num_layers=12, patch_dim=768, pos_grid=24, num_extra_tokens=0,
+                num_scales=0, use_layer_scale=0, calibrate=1, diff_scale=1, num_rgs=4, num_rcabs=4, ca_hidden=96, precision=1)
+    create = lib.vtq_create
+    create.argtypes = [C.c_void_p, C.c_void_p]
+    h = C.c_void_p()
+    assert create(None, C.byref(h)) != 0 and b"null" in lib.vtq_last_error()
+    for field, bad, text in [("hidden_size", 512, b"hidden_size"), ("num_heads", 8, b"head_dim"), ("mlp_dim", 1000, b"mlp_dim"),
+                             ("patch_dim", 192, b"patch_dim"), ("num_layers", 0, b"topology"), ("ca_hidden", 3, b"DiffNet"),
+                             ("precision", 7, b"precision")]:
+        cfg = Cfg(**{**good, field: bad})
+        assert create(C.byref(cfg), C.byref(h)) != 0, field
+        assert text in lib.vtq_last_error(), (field, lib.vtq_last_error())
+    # null handle / null tensors
+    assert lib.vtq_forward(None, None, None, None, None, None, None, 1, 1, None, None) != 0
+    assert lib.vtq_load_weights(None, None, 0, None) != 0
+    assert lib.vtq_reserve(None, 1, 1) != 0
+    assert lib.vtq_workspace_bytes(None, 1, 1) == 0
+    assert lib.vtq_k_gemm_schedule(256, 100, None, 0) == -1
