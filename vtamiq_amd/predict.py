@@ -26,47 +26,46 @@ def get_data_tuple(batch, device):
 
 
 def split_per_image(x, has_batch_dim=True, clone=True):
-    """train.py:258-267 -- (B,K,...) -> K tensors (B,...), cloned to contiguous."""
-    num_images = x.shape[1] if has_batch_dim else x.shape[0]
-
-    def x_i(i):
-        return x[:, i] if has_batch_dim else x[i].unsqueeze(0)
-    return tuple((x_i(i).clone() if clone else x_i(i)) for i in range(num_images))
+    """train.py:258-267 -- a stacked (B, K, ...) tensor (or (K, ...) without batch dimension, which gains a leading 1) as K
+    per-image tensors; `clone` makes each one contiguous (the engine needs that, the reference's .view() calls too)."""
+    axis = 1 if has_batch_dim else 0
+    pieces = x.unbind(axis)
+    if not has_batch_dim:
+        pieces = tuple(t.unsqueeze(0) for t in pieces)
+    return tuple(t.clone() for t in pieces) if clone else tuple(pieces)
 
 
 def model_forward(model, model_name, patches, pos, scales):
-    """train.py:270-275."""
-    if "vtamiq" in model_name.lower():
-        return model(patches, pos, scales)
-    raise ValueError(f"Unsupported model {model_name}")
+    """train.py:270-275 -- dispatch by model name; only VTAMIQ exists on this path."""
+    if "vtamiq" not in model_name.lower():
+        raise ValueError(f"Unsupported model {model_name}")
+    return model(patches, pos, scales)
 
 
 def predict(model, pref_module, data, is_pairwise, output_feats, use_scales):
-    """train.py:278-314.  Returns (q, q_p, feats)."""
-    q, patches, pos, scales = data[:4]
-    if is_pairwise:
-        pref, pdist1, pdist2 = split_per_image(patches)
-        posref, posdist1, posdist2 = split_per_image(pos)
-        scalesref, scalesdist1, scalesdist2 = split_per_image(scales) if use_scales else (None, None, None)
-        if hasattr(model, "forward_pairwise"):
-            # same scores as the two calls of train.py:286-287, with the shared reference image encoded once
-            q1, q2 = model.forward_pairwise((pref, pdist1, pdist2), (posref, posdist1, posdist2),
-                                            (scalesref, scalesdist1, scalesdist2) if use_scales else None)
-            feats = (None, None) if output_feats else None
-        else:
-            out1 = model((pref, pdist1), (posref, posdist1), (scalesref, scalesdist1))
-            out2 = model((pref, pdist2), (posref, posdist2), (scalesref, scalesdist2))
-            q1, q2 = out1[0], out2[0]
-            feats = (out1[1], out2[1]) if output_feats else None
-        if pref_module is not None:
-            q_p = pref_module(q1, q2)
-        else:
-            q_p = torch.sigmoid(q1 - q2)          # sign convention of train.py:301 (differs from :298 -- reproduced)
+    """train.py:278-314.  `data` = (q, patches, pos, scales, ...) as produced by get_data_tuple; returns (q, q_p, feats) with
+    q_p flattened.  FR items: q_p is the model's score.  Pairwise items (ref, dist1, dist2): q_p is the preference,
+    pref_module(q1, q2) when a module is given, otherwise sigmoid(q1 - q2) -- the reference's two branches disagree in sign
+    (train.py:298 vs :301, PreferenceModule computes sigmoid(p (q2 - q1))); that is reproduced, not fixed."""
+    q_true, stacked_patches, stacked_pos, stacked_scales = data[:4]
+    per_image = [split_per_image(stacked_patches), split_per_image(stacked_pos),
+                 split_per_image(stacked_scales) if use_scales else None]
+    if not is_pairwise:
+        scales = per_image[2] if use_scales else (None, None)
+        out = model(per_image[0], per_image[1], scales)
+        q_p, feats = (out[0], out[1]) if output_feats else (out[0], None)
+        return q_true, q_p.flatten(), feats
+
+    triplet = lambda k: tuple(per_image[k]) if per_image[k] is not None else (None, None, None)      # noqa: E731
+    (p_ref, p_d1, p_d2), (x_ref, x_d1, x_d2), (s_ref, s_d1, s_d2) = triplet(0), triplet(1), triplet(2)
+    if hasattr(model, "forward_pairwise"):
+        # same scores as the reference's two model calls (train.py:286-287), the shared reference image encoded once
+        q1, q2 = model.forward_pairwise((p_ref, p_d1, p_d2), (x_ref, x_d1, x_d2), (s_ref, s_d1, s_d2) if use_scales else None)
+        feats = (None, None) if output_feats else None
     else:
-        patches = split_per_image(patches)
-        pos = split_per_image(pos)
-        scales = split_per_image(scales) if use_scales else (None, None)
-        out = model(patches, pos, scales)
-        q_p, feats = out if output_feats else (out[0], None)
-    q_p = q_p.flatten()
-    return q, q_p, feats
+        first = model((p_ref, p_d1), (x_ref, x_d1), (s_ref, s_d1))
+        second = model((p_ref, p_d2), (x_ref, x_d2), (s_ref, s_d2))
+        q1, q2 = first[0], second[0]
+        feats = (first[1], second[1]) if output_feats else None
+    q_p = pref_module(q1, q2) if pref_module is not None else torch.sigmoid(q1 - q2)
+    return q_true, q_p.flatten(), feats
