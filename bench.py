@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-pairs/sec of the VTAMIQ ViT-B/16 pair forward (P=500 patches) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--patches P] [--precision bf16x3|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--patches P] [--precision bf16x3|bf16|fp8w]
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); every rank scores its own shard of the global batch
-(weak scaling: per-GPU batch fixed) and one RCCL all-gather of the scores closes each step.  Inputs are synthetic and
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+One process per GPU; every rank scores its own shard of the global batch (weak scaling: per-GPU batch fixed) and one RCCL
+all-gather of the scores closes each step.  Two ways to get the N ranks:
+  * the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK/LOCAL_RANK/WORLD_SIZE set);
+  * `python bench.py --gpus N` on its own: the parent process starts the N ranks itself as child processes BEFORE it makes
+    any GPU call (never an exec from a process that touched the GPU), forwards rank 0's JSON line and exits non-zero if
+    any rank failed.
+Inputs are synthetic and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -17,9 +23,76 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6        # dense bf16 MFMA: 256 CU x 4096 flop/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
+MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0}
 
 
-def synth_inputs_on_device(torch, spec, B, N, device, seed):
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N without torchrun
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int, argv, timeout_s: float) -> int:
+    """Start n rank processes (this script, same argv) with the torch.distributed env contract, wait, forward rank 0's
+    stdout.  The parent never imports torch or touches the GPU.  Children are stopped by PID if one fails or time runs out."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    deadline = time.time() + timeout_s
+    rc = 0
+    out0 = ""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if r == 0:
+                        out0 = procs[0].stdout.read()
+                    if code != 0:
+                        rc = rc or code or 1
+                        print(f"[bench] rank {r} exited with code {code}", file=sys.stderr)
+            if rc or time.time() > deadline:
+                if not rc:
+                    print(f"[bench] ranks {sorted(pending)} still running after {timeout_s:.0f} s", file=sys.stderr)
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                       # exact PIDs only
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if not out0 and procs[0].stdout and not procs[0].stdout.closed:
+        try:
+            out0 = procs[0].stdout.read()
+        except Exception:
+            pass
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench] rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_inputs_on_device(torch, B, N, device, seed):
     """ref ~ U(-1,1); dist = clamp(ref + 0.1 N(0,1)); pos ~ U(0,1) <= 1-1e-6 shared (aligned)."""
     g = torch.Generator(device=device).manual_seed(seed)
     ref = torch.rand(B, N, 3, 16, 16, device=device, generator=g) * 2 - 1
@@ -29,14 +102,16 @@ def synth_inputs_on_device(torch, spec, B, N, device, seed):
 
 
 def fc1_traffic(precision, B):
-    """HBM bytes of ONE full-batch fc1 GEMM (M = 2*B*S_pad rows) from the committed PMC passes
-    (profiles/r01_gemm_fc1_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected at B=32 in separate
-    rocprofv3 --pmc runs); scaled linearly with the batch."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_fc1_traffic.json")))
-        return d[precision]["bytes_per_launch"] * (B / 32.0)
-    except Exception:
-        return None
+    """HBM bytes of ONE full-batch fc1 GEMM from the committed PMC passes (profiles/*_gemm_fc1_traffic.json: FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs at B=32), scaled linearly with the batch.  A committed
+    measurement of the same kernel, not a counter read during this run (rocprofv3 is not on bench.py's path)."""
+    for name in ("r02_gemm_fc1_traffic.json", "r01_gemm_fc1_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return d[precision]["bytes_per_launch"] * (B / 32.0), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def effective_cores():
@@ -51,35 +126,40 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(torch, spec, sd_np, N, seconds_budget=25.0):
-    """The oracle (CPU port of the reference path, fp32, torch CPU ops) timed on this host's cores on a bounded sample:
-    one pair (two 500-patch images through all layers) per forward; thread count = usable cores capped at 64 (torch's
-    intra-op pool stops scaling and oversubscribes far earlier on this shape)."""
+def cpu_baseline(torch, spec, sd_np, seconds_budget=28.0):
+    """the oracle (fp32 torch-CPU port of the reference path, kind "port") on this host's cores, eval/no-grad,
+    at C1 (B=2, N=50) and B=8, N=500, with n = all usable cores and n = 8 threads.  Bounded: the B=8 rows are one warm-up +
+    as many forwards as fit the budget (>= 1).  `value` = the B=8, N=500 rate on all cores."""
     from oracle import vtamiq_oracle as O
     from vtamiq_amd import synth
     ncores = min(effective_cores(), 64)
-    torch.set_num_threads(ncores)
     sd = O.to_torch(sd_np)
-    Bc = 1
-    patches, pos, _ = synth.make_inputs(spec, Bc, N, 4242)
-    tp, tq = torch.from_numpy(patches), torch.from_numpy(pos)
-    args = ((tp[:, 0], tp[:, 1]), (tq[:, 0], tq[:, 1]), (None, None))
-    t0 = time.perf_counter()
-    O.vtamiq_forward(sd, spec, *args)                       # warm-up (also bounds the sample)
-    warm = time.perf_counter() - t0
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 7 and (time.perf_counter() - t_start + warm) < seconds_budget:
+    cases = []
+    t_begin = time.perf_counter()
+    threads = sorted({ncores, min(8, ncores)}, reverse=True)
+    plan = [("C1", 2, 50, n, 5) for n in threads] + [("B8N500", 8, 500, n, 3 if n == ncores else 2) for n in threads]
+    for name, Bc, Nc, nthr, reps in plan:
+        nthr = min(nthr, ncores)
+        torch.set_num_threads(nthr)
+        patches, pos, _ = synth.make_inputs(spec, Bc, Nc, 4242)
+        tp, tq = torch.from_numpy(patches), torch.from_numpy(pos)
+        args = ((tp[:, 0], tp[:, 1]), (tq[:, 0], tq[:, 1]), (None, None))
         t0 = time.perf_counter()
-        O.vtamiq_forward(sd, spec, *args)
-        times.append(time.perf_counter() - t0)
-    if not times:
-        times = [warm]
-    med = sorted(times)[len(times) // 2]
-    return {"value": Bc / med, "unit": "image-pairs/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle fp32 (torch CPU ops), {Bc} pair x {N} patches ViT-B/16 L={spec.num_layers}, "
-                      f"1 warm-up + median of {len(times)} forwards, {ncores} threads",
-            "ms_per_forward": med * 1e3}
+        O.vtamiq_forward(sd, spec, *args)                   # warm-up
+        warm = time.perf_counter() - t0
+        times = []
+        while len(times) < reps and (not times or time.perf_counter() - t_begin + warm < seconds_budget):
+            t0 = time.perf_counter()
+            O.vtamiq_forward(sd, spec, *args)
+            times.append(time.perf_counter() - t0)
+        med = sorted(times)[len(times) // 2]
+        cases.append({"case": name, "B": Bc, "N": Nc, "threads": nthr, "ms_per_forward": med * 1e3, "pairs_per_s": Bc / med,
+                      "forwards_timed": len(times)})
+    head = [c for c in cases if c["case"] == "B8N500"][0]
+    return {"value": head["pairs_per_s"], "unit": "image-pairs/s", "cores": head["threads"], "kind": "port",
+            "sample": f"oracle fp32 (torch CPU ops), ViT-B/16 L={spec.num_layers}: B=8 x N=500 on {head['threads']} threads "
+                      f"(1 warm-up + median of {head['forwards_timed']}); all rows in `cases`",
+            "ms_per_forward": head["ms_per_forward"], "cases": cases}
 
 
 def main():
@@ -92,54 +172,61 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("VTAMIQ_BENCH_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are stopped")
+    # launcher self-test on CPU (tests/test_bench_launcher.py): gloo ranks + a stub model, no HIP anywhere
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:], a.launch_timeout))
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from vtamiq_amd import VTAMIQ, synth
     from vtamiq_amd.dist import gather_scores
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = a.backend == "nccl"
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("VTQ_BENCH_FAIL_RANK") == str(rank):          # launcher test hook: this rank dies before the first collective
+        sys.exit(3)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     B, N = a.batch, a.patches
-    kw = dict(vit_config=dict(variant="ViT-B16"))                 # L=12, T=1, r=8: BASELINE configs 2/3 and north star
-    spec_model = VTAMIQ(**json.loads(json.dumps(kw)), precision=a.precision)
-    spec = spec_model.spec
-    sd_np = synth.make_state_dict(spec, 0)
-    state = {k: torch.from_numpy(v) for k, v in sd_np.items()}
-
-    def make_model(precision):
-        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
-        m.load_state_dict(state)
-        return m.to(device).eval()
-
-    inputs = synth_inputs_on_device(torch, spec, B, N, device, 1234 + rank)
     global_batch = B * world
+    inputs = synth_inputs_on_device(torch, B, N, device, 1234 + rank)
 
-    def run(model, steps, warmup, profile_class=None):
+    def run(model, steps, warmup, inp=inputs, gb=global_batch, profile_class=None):
         with torch.no_grad():
             for _ in range(warmup):
-                q = gather_scores(model(*inputs)[0], global_batch)
-            torch.cuda.synchronize()
+                q = gather_scores(model(*inp)[0], gb)
+            sync()
             if profile_class:
                 model.profile_enable([profile_class])
             if world > 1:
                 dist.barrier()
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for _ in range(steps):
-                q = gather_scores(model(*inputs)[0], global_batch)
-            torch.cuda.synchronize()
+                q = gather_scores(model(*inp)[0], gb)
+            sync()
             if world > 1:
                 dist.barrier()
             dt = time.perf_counter() - t0
@@ -152,29 +239,60 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), q, prof
 
+    if a.stub:                                # launcher / collective plumbing only; never a measurement
+        from tests.bench_stub import StubModel
+        dt, q, _ = run(StubModel(), a.steps, a.warmup)
+        assert q.shape == (global_batch,)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test (stub model, no HIP)", "value": global_batch * a.steps / dt,
+                              "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32", "data": "stub", "rccl_ranks": rccl_ranks, "backend": a.backend,
+                              "config": {"workload": "stub", "global_batch": global_batch, "parallelism": f"dp{world}"},
+                              "q_checksum": float(q.double().sum())}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from vtamiq_amd import VTAMIQ, synth
+    kw = dict(vit_config=dict(variant="ViT-B16"))                 # L=12, T=1, r=8: BASELINE configs 2/3 and north star
+    spec = VTAMIQ(**json.loads(json.dumps(kw)), precision=a.precision).spec
+    sd_np = synth.make_state_dict(spec, 0)
+    state = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+
+    def make_model(precision):
+        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+        m.load_state_dict(state)
+        return m.to(device).eval()
+
     model = make_model(a.precision)
     DOM = "fc1"
-    dt, q, prof = run(model, a.steps, a.warmup, DOM)
+    dt, q, prof = run(model, a.steps, a.warmup, profile_class=DOM)
     assert q.shape == (global_batch,) and bool(torch.isfinite(q).all())
     pairs_per_s = global_batch * a.steps / dt
     f_pair = spec.flops_per_pair(N)                      # algorithmic (SURVEY 8d / BASELINE.md)
     pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
     f_exec = spec.flops_per_pair_executed(N, cls_prune=pruned)
     S = spec.seq_len(N)
+    mfma_frac = lambda pps: pps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)
+    other = "bf16" if a.precision == "bf16x3" else "bf16x3"
 
     out = {
         "metric": "image-pairs/sec ViT-B/16 P=500 patches, 1->8 MI355X; % bf16 MFMA roofline",
         "value": pairs_per_s, "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
+        "dtype": "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
+        "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
                                f"{N} patches of 16x16x3, random-init seeded weights",
                    "global_batch": global_batch, "patches": N, "seq_len": S, "parallelism": f"dp{world}",
                    "numerics": a.precision,
-                   "numerics_note": "bf16x3 = hi/lo bf16 operand split, 3 bf16 MFMAs per product, fp32 accumulate (meets 1e-3 "
-                                    "parity); bf16 = 1 MFMA per product (throughput mode, parity ~3e-2)"},
+                   "numerics_note": "bf16x3 = hi/lo bf16 operand split, 3 bf16 MFMAs per product, fp32 accumulate: the only mode "
+                                    "within the north-star 1e-3 of the fp32 CPU reference, so it is `value`; by construction it can "
+                                    "reach at most 1/3 of the single-bf16 MFMA roofline (roofline.mode_cap).  bf16 = 1 MFMA per "
+                                    "product (throughput mode, parity ~3e-2, reported in other_mode, never claimed as parity)"},
         # executed flops: the last layer runs Q/attention/out-proj/MLP for the CLS row only (legal: only token 0 is consumed)
-        "forward_mfma_frac": pairs_per_s / world * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+        "forward_mfma_frac": mfma_frac(pairs_per_s),
         "flops_per_pair": f_pair, "flops_per_pair_executed": f_exec,
     }
 
@@ -184,38 +302,45 @@ def main():
         per_step = launches / steps
         flops_launch = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim * full_layers / per_step    # algorithmic, unpadded rows
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
-        traffic = fc1_traffic(a.precision, B)
-        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{3 if a.precision == 'bf16x3' else 1}, GELU> (fc1 of every full layer)",
+        traffic, src = fc1_traffic(a.precision, B)
+        mpp = MFMA_PER_PRODUCT[a.precision]
+        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{int(mpp)}, GELU> (fc1 of every full layer)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                "traffic": traffic * full_layers / per_step if traffic else None, "avg_launch_ms": ms_sum / launches,
-                "launches": int(launches), "launches_per_step": per_step, "flops_per_launch": flops_launch,
-                # bf16x3 issues 3 bf16 MFMAs per algorithmic product, so its algorithmic frac is capped at 1/3
-                "mfma_issue_frac": ach * (3 if a.precision == "bf16x3" else 1) / PEAK_BF16_TFLOPS, "note": note}
+                "traffic": traffic * full_layers / per_step if traffic else None, "traffic_source": src,
+                # the numerics ceiling: bf16x3 issues 3 bf16 MFMAs per algorithmic product
+                "mode_cap": 1.0 / mpp, "frac_of_mode_cap": ach / PEAK_BF16_TFLOPS * mpp,
+                "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
+                "flops_per_launch": flops_launch, "note": note}
 
     if prof and prof[1] > 0:
-        in_region = roofline_of(prof, a.steps, "HIP events inside the timed region of `value`: two part-batches run on two streams, so a "
-                                "launch covers half the rows and shares the chip with the other stream's kernels")
-        # the same kernel alone on the chip: a second timed region with ONE part-batch (full-batch launches on one stream)
-        os.environ["VTQ_PARTS"] = "1"
-        model_iso = make_model(a.precision)
-        iso_steps = max(3, a.steps // 2)
-        _, _, prof_iso = run(model_iso, iso_steps, 2, DOM)      # the engine is created lazily on the first forward
-        os.environ.pop("VTQ_PARTS")
-        out["roofline"] = roofline_of(prof_iso, iso_steps, "HIP events on the launch stream over a timed region with one part-batch "
-                                      "(VTQ_PARTS=1): the kernel alone on the chip, full-batch launches")
-        out["roofline"]["in_value_region"] = {k: in_region[k] for k in ("achieved", "frac", "avg_launch_ms", "launches_per_step", "note")}
-        del model_iso
-        torch.cuda.empty_cache()
+        out["roofline"] = roofline_of(prof, a.steps, "HIP events recorded by the engine on the launch stream around every fc1 launch "
+                                      "of the timed region of `value`")
     if not a.no_second_mode:                     # every rank: run() is collective
-        other = "bf16" if a.precision == "bf16x3" else "bf16x3"
         del model
         torch.cuda.empty_cache()
         model2 = make_model(other)
         dt2, q2, _ = run(model2, a.steps, a.warmup)
         out["other_mode"] = {"numerics": other, "value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
-                             "forward_mfma_frac": global_batch * a.steps / dt2 / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)}
+                             "forward_mfma_frac": mfma_frac(global_batch * a.steps / dt2)}
+        del model2
+        torch.cuda.empty_cache()
     else:
         q2 = None
+    if not a.no_north_star and world == 1:
+        # BASELINE north-star operating point: B = 64 pairs on one GPU, both numerics modes (the >= 40 % target is stated on it)
+        Bn = 64
+        inp64 = synth_inputs_on_device(torch, Bn, N, device, 4321)
+        ns = {"batch": Bn, "patches": N, "target_forward_mfma_frac": 0.40}
+        for prec in (a.precision, other):
+            m = make_model(prec)
+            nsteps = max(3, a.steps // 2)
+            dtn, _, _ = run(m, nsteps, 2, inp=inp64, gb=Bn)
+            ns[prec] = {"value": Bn * nsteps / dtn, "unit": "image-pairs/s", "ms_per_step": dtn / nsteps * 1e3,
+                        "forward_mfma_frac": Bn * nsteps / dtn * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+                        "mode_cap": 1.0 / MFMA_PER_PRODUCT[prec]}
+            del m
+            torch.cuda.empty_cache()
+        out["north_star_point"] = ns
     if rank == 0:
         # parity of both modes on the first pairs of rank 0's shard, against the oracle on the host (not timed)
         from oracle import vtamiq_oracle as O
@@ -231,9 +356,9 @@ def main():
             return {"max_rel": float(np.max(d / np.abs(q_ref))), "max_rel_rms": float(d.max() / rms), "max_abs": float(d.max())}
         out["parity_vs_cpu_oracle"] = {a.precision: perr(q)}
         if q2 is not None:
-            out["parity_vs_cpu_oracle"][out["other_mode"]["numerics"]] = perr(q2)
+            out["parity_vs_cpu_oracle"][other] = perr(q2)
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np, N)
+            out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,62 @@
+"""bench.py --gpus N without torchrun: the parent starts the ranks itself (before any GPU call), forwards rank 0's single JSON
+line and propagates failures.  Driven here on CPU: gloo ranks + tests/bench_stub.py (no HIP anywhere)."""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def _expected_checksum(world, B, N):
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests.bench_stub import StubModel
+    tot = 0.0
+    for r in range(world):
+        inp = bench.synth_inputs_on_device(torch, B, N, torch.device("cpu"), 1234 + r)
+        tot += float(StubModel()(*inp)[0].double().sum())
+    return tot
+
+
+def test_self_launch_two_gloo_ranks():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3", "--patches", "5", "--backend", "gloo", "--stub"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_batch"] == 6 and d["steps"] == 3
+    assert d["data"] == "stub" and d["scaling"] == "weak"
+    # every rank's shard reached rank 0 through the all-gather, in rank order
+    assert abs(d["q_checksum"] - _expected_checksum(2, 3, 5)) < 1e-4
+
+
+def test_single_rank_needs_no_launcher():
+    p = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--patches", "4", "--backend", "gloo", "--stub"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
+
+
+def test_failing_rank_fails_the_launch():
+    # WORLD_SIZE mismatch inside the children (the assert in bench.main) must surface as a non-zero exit, with no hang
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--patches", "4", "--backend", "gloo", "--stub",
+              "--launch-timeout", "60"], env_extra={"VTQ_BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_under_torchrun_env_no_relaunch():
+    # with RANK set (the driver's torch.distributed.run path) bench.py must NOT spawn: world 1 here
+    p = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "2", "--patches", "4", "--backend", "gloo", "--stub"],
+             env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
