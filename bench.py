@@ -23,7 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6        # dense bf16 MFMA: 256 CU x 4096 flop/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
-MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0}
+# MFMAs per product of the linear layers (the dominant kernel is a linear layer): vtamiq_amd/_lib.py MFMA_TERMS
+MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0, "fp16": 1.0, "fp16x2": 2.0, "fp16x3": 3.0}
+HEADLINE = "fp16x3"          # default `value` mode; OTHER_MODES are timed beside it
+OTHER_MODES = ("fp16x2", "fp16")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -169,7 +172,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU (BASELINE config 2: 32)")
     ap.add_argument("--patches", type=int, default=500)
-    ap.add_argument("--precision", default=os.environ.get("VTAMIQ_BENCH_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("VTAMIQ_BENCH_PRECISION", HEADLINE), choices=sorted(MFMA_PER_PRODUCT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
@@ -256,7 +259,7 @@ def main():
         return
 
     from vtamiq_amd import VTAMIQ, synth
-    kw = dict(vit_config=dict(variant="ViT-B16"))                 # L=12, T=1, r=8: BASELINE configs 2/3 and north star
+    kw = dict(vit_config=dict(variant="ViT-B16", pretrained=False))   # L=12, T=1, r=8: BASELINE configs 2/3 and north star; seeded weights
     spec = VTAMIQ(**json.loads(json.dumps(kw)), precision=a.precision).spec
     sd_np = synth.make_state_dict(spec, 0)
     state = {k: torch.from_numpy(v) for k, v in sd_np.items()}
@@ -276,21 +279,23 @@ def main():
     f_exec = spec.flops_per_pair_executed(N, cls_prune=pruned)
     S = spec.seq_len(N)
     mfma_frac = lambda pps: pps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)
-    other = "bf16" if a.precision == "bf16x3" else "bf16x3"
+    others = [m for m in OTHER_MODES if m != a.precision]
 
     out = {
         "metric": "image-pairs/sec ViT-B/16 P=500 patches, 1->8 MI355X; % bf16 MFMA roofline",
         "value": pairs_per_s, "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
+        "dtype": "f16" if a.precision.startswith("fp16") else "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
                                f"{N} patches of 16x16x3, random-init seeded weights",
                    "global_batch": global_batch, "patches": N, "seq_len": S, "parallelism": f"dp{world}",
                    "numerics": a.precision,
-                   "numerics_note": "bf16x3 = hi/lo bf16 operand split, 3 bf16 MFMAs per product, fp32 accumulate: the only mode "
-                                    "within the north-star 1e-3 of the fp32 CPU reference, so it is `value`; by construction it can "
-                                    "reach at most 1/3 of the single-bf16 MFMA roofline (roofline.mode_cap).  bf16 = 1 MFMA per "
-                                    "product (throughput mode, parity ~3e-2, reported in other_mode, never claimed as parity)"},
+                   "numerics_note": "16-bit MFMA operands (fp16 and bf16 MFMAs run at the same rate; peak = the bf16 dense peak), fp32 "
+                                    "accumulate, fp32 LayerNorm/softmax/GELU/residual.  fp16x3 = hi/lo fp16 split of both operands, 3 "
+                                    "MFMAs per product (scores at the fp32 reference's own noise floor); fp16x2 = activations split, "
+                                    "weights single fp16 in the linear layers, 2 MFMAs per product (attention stays 3-term); fp16 / "
+                                    "bf16 = 1 MFMA per product (throughput modes, outside the 1e-3 parity tolerance, never claimed as "
+                                    "parity).  A k-MFMA mode can reach at most 1/k of the MFMA roofline (roofline.mode_cap)"},
         # executed flops: the last layer runs Q/attention/out-proj/MLP for the CLS row only (legal: only token 0 is consumed)
         "forward_mfma_frac": mfma_frac(pairs_per_s),
         "flops_per_pair": f_pair, "flops_per_pair_executed": f_exec,
@@ -304,7 +309,7 @@ def main():
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
         traffic, src = fc1_traffic(a.precision, B)
         mpp = MFMA_PER_PRODUCT[a.precision]
-        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{int(mpp)}, GELU> (fc1 of every full layer)",
+        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{'f16' if a.precision.startswith('fp16') else 'bf16'}, {int(mpp)}, GELU> (fc1 of every full layer)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": traffic * full_layers / per_step if traffic else None, "traffic_source": src,
                 # the numerics ceiling: bf16x3 issues 3 bf16 MFMAs per algorithmic product
@@ -315,23 +320,26 @@ def main():
     if prof and prof[1] > 0:
         out["roofline"] = roofline_of(prof, a.steps, "HIP events recorded by the engine on the launch stream around every fc1 launch "
                                       "of the timed region of `value`")
+    q_other = {}
     if not a.no_second_mode:                     # every rank: run() is collective
         del model
         torch.cuda.empty_cache()
-        model2 = make_model(other)
-        dt2, q2, _ = run(model2, a.steps, a.warmup)
-        out["other_mode"] = {"numerics": other, "value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
-                             "forward_mfma_frac": mfma_frac(global_batch * a.steps / dt2)}
-        del model2
-        torch.cuda.empty_cache()
-    else:
-        q2 = None
+        out["other_modes"] = {}
+        for other in others:
+            model2 = make_model(other)
+            dt2, q2, _ = run(model2, a.steps, a.warmup)
+            q_other[other] = q2
+            out["other_modes"][other] = {"value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
+                                         "forward_mfma_frac": mfma_frac(global_batch * a.steps / dt2),
+                                         "mfma_per_product_linear": MFMA_PER_PRODUCT[other]}
+            del model2
+            torch.cuda.empty_cache()
     if not a.no_north_star and world == 1:
-        # BASELINE north-star operating point: B = 64 pairs on one GPU, both numerics modes (the >= 40 % target is stated on it)
+        # BASELINE north-star operating point: B = 64 pairs on one GPU, every numerics mode (the >= 40 % target is stated on it)
         Bn = 64
         inp64 = synth_inputs_on_device(torch, Bn, N, device, 4321)
         ns = {"batch": Bn, "patches": N, "target_forward_mfma_frac": 0.40}
-        for prec in (a.precision, other):
+        for prec in [a.precision] + others:
             m = make_model(prec)
             nsteps = max(3, a.steps // 2)
             dtn, _, _ = run(m, nsteps, 2, inp=inp64, gb=Bn)
@@ -355,7 +363,7 @@ def main():
             d = np.abs(qq[:nchk].cpu().numpy() - q_ref)
             return {"max_rel": float(np.max(d / np.abs(q_ref))), "max_rel_rms": float(d.max() / rms), "max_abs": float(d.max())}
         out["parity_vs_cpu_oracle"] = {a.precision: perr(q)}
-        if q2 is not None:
+        for other, q2 in q_other.items():
             out["parity_vs_cpu_oracle"][other] = perr(q2)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np)

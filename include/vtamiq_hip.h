@@ -23,11 +23,25 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 1
+#define VTQ_ABI_VERSION 2
 
-/* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in both) */
-#define VTQ_PREC_BF16   0   /* one bf16 MFMA per product: the throughput mode                          */
-#define VTQ_PREC_BF16X3 1   /* operands split hi+lo bf16, hi*hi + lo*hi + hi*lo: meets 1e-3 vs fp32 CPU */
+/* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
+ * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
+ * own GPU path uses for these contractions (torch.cuda.amp.autocast(float16), train.py:602). */
+#define VTQ_PREC_BF16   0   /* one bf16 MFMA per product                                                                      */
+#define VTQ_PREC_BF16X3 1   /* operands split hi+lo bf16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (3 MFMAs)                          */
+#define VTQ_PREC_FP16   2   /* one fp16 MFMA per product                                                                      */
+#define VTQ_PREC_FP16X3 3   /* operands split hi+lo fp16, 3 MFMAs per product: at the fp32 reference's own noise floor         */
+#define VTQ_PREC_FP16X2 4   /* linear layers: activations split hi+lo fp16, weights single fp16 (2 MFMAs per product);         */
+                            /* attention (QK^T, PV): the 3-term fp16 form                                                      */
+
+/* operand-format code of the per-kernel entry points: MFMAs per product (1 | 2 | 3) + 16 for fp16 planes (0 = bf16):
+ *   1 / 17 single plane each; 18 = activation hi/lo planes x single weight plane (fp16 only); 3 / 19 = hi/lo planes for both */
+#define VTQ_NUM_BF16   1
+#define VTQ_NUM_BF16X3 3
+#define VTQ_NUM_FP16   17
+#define VTQ_NUM_FP16X2 18
+#define VTQ_NUM_FP16X3 19
 
 typedef struct vtq_config {
     int32_t hidden_size;       /* 768 | 1024                (transformer.py:68-98)                    */
@@ -90,6 +104,11 @@ int  vtq_forward(vtq_handle h,
 int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float* const* pos, const float* const* scales,
                           int32_t B, int32_t N, float* q_out, void* stream);
 
+/* Input check.  The reference raises (IndexError / device assert) when a position lies outside [0, 1)
+ * (transformer.py:417-421); vtq_forward clamps such an index into the table instead of gathering out of bounds and records it.
+ * This call synchronises `stream`, returns the flags accumulated since the last call (bit 0: position out of range) and clears them. */
+int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
+
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors
  * vit_config["return_layers"] (transformer.py:369-372, 632-636). */
@@ -112,31 +131,33 @@ int  vtq_profile_enable(vtq_handle h, uint32_t class_mask);
 int  vtq_profile_collect(vtq_handle h, double* ms_sum, int64_t* launches);
 
 /* ---- per-kernel entry points (unit tests call these through the same ABI) ----------------------------- */
-/* fp32 [rows, cols] -> bf16 planes: dst (hi) and, when nsplit == 3, dst + plane_stride (lo). */
-int  vtq_k_split_bf16(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t nsplit, void* stream);
+/* fp32 [rows, cols] -> 16-bit planes (f16: 0 = bf16, 1 = fp16): dst (hi) and, when planes == 2, dst + plane_stride (lo). */
+int  vtq_k_split(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t f16, int32_t planes, void* stream);
 
-/* C[M,N] = A[M,K] * W[N,K]^T (+epilogue); A/W are bf16 planes as above; M%256==0, N%256==0, K%64==0.
- *   epilogue 0: out_bf16 = acc + bias
- *            1: out_bf16 = gelu_erf(acc + bias)                            (transformer.py:212-215)
- *            2: x_f32   += gamma * (acc + bias)   (gamma NULL = 1)         (transformer.py:279,284) */
+/* C[M,N] = A[M,K] * W[N,K]^T (+epilogue); A/W are 16-bit planes as above, format `num` = VTQ_NUM_*; M%256==0, N%256==0,
+ * K%128==0 (one MFMA per product) or K%64==0.
+ *   epilogue 0: out16  = acc + bias                 (1 or 2 planes, as the activations of `num`)
+ *            1: out16  = gelu_erf(acc + bias)                              (transformer.py:212-215)
+ *            2: x_f32 += gamma * (acc + bias)   (gamma NULL = 1)           (transformer.py:279,284) */
 int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane,
-                int32_t M, int32_t N, int32_t K, int32_t nsplit, int32_t epilogue,
+                int32_t M, int32_t N, int32_t K, int32_t num, int32_t epilogue,
                 const float* bias, const float* gamma, float* x_f32,
-                void* out_bf16, int64_t o_plane, int32_t ldo, void* stream);
+                void* out16, int64_t o_plane, int32_t ldo, void* stream);
 
-/* HOST-only: the block order vtq_k_gemm uses for an [M, N] output (M, N multiples of 256): out[i] = (tile << 2) | kind with
- * tile = row_tile * (N/256) + col_tile, kind 0 = 256x256 tile, 1 / 2 = its top / bottom 128 rows.  Returns the number of
- * blocks (writes at most cap entries; out may be NULL), or -1 on a bad shape.  No GPU needed. */
-int  vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t* out, int32_t cap);
+/* HOST-only: the persistent schedule vtq_k_gemm uses for an [M, N] output (M, N multiples of 256) with K columns and `wplanes`
+ * weight planes: out[0..256] = begin offsets of the 256 workgroups' lists (out[256] = total length), then the lists:
+ * entry = (tile << 2) | kind with tile = row_tile * (N/256) + col_tile, kind 0 = 256x256 tile, 1 / 2 = its top / bottom 128 rows.
+ * Returns the total length (writes at most cap entries; out may be NULL), or -1 on a bad shape.  No GPU needed. */
+int  vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t K, int32_t wplanes, int32_t* out, int32_t cap);
 
-/* LayerNorm(eps=1e-6) rows of x[rows, H] fp32 -> bf16 planes (transformer.py:253-254, 276, 281). */
+/* LayerNorm(eps=1e-6) rows of x[rows, H] fp32 -> 16-bit planes (transformer.py:253-254, 276, 281). */
 int  vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane,
-                     int32_t rows, int32_t H, int32_t nsplit, void* stream);
+                     int32_t rows, int32_t H, int32_t f16, int32_t planes, void* stream);
 
-/* softmax(Q K^T / sqrt(64)) V per (sequence, head) on the packed qkv[rows, 3H] bf16 planes; sequences are
- * S_pad rows apart, keys >= S are masked; out[rows, H] bf16 planes, heads merged (transformer.py:153-166). */
+/* softmax(Q K^T / sqrt(64)) V per (sequence, head) on the packed qkv[rows, 3H] planes (num = VTQ_NUM_* with 1 or 3 terms);
+ * sequences are S_pad rows apart, keys >= S are masked; out[rows, H] planes, heads merged (transformer.py:153-166). */
 int  vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane,
-                     int32_t nseq, int32_t S, int32_t S_pad, int32_t H, int32_t nsplit, void* stream);
+                     int32_t nseq, int32_t S, int32_t S_pad, int32_t H, int32_t num, void* stream);
 
 /* fp32 small-batch linear of the DiffNet head: y[b][n] = post(W[n] . pre(x[b]) + bias[n]) (+ res[b][n]); pre/post = PReLU
  * with the given one-element slope tensors (NULL = identity).  Conv1d(k=1) on (B,C,1) (channel_attention.py:45, 58-61). */

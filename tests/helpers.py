@@ -53,6 +53,16 @@ def rel_err(q, q_ref):
                 max_abs=float(d.max()), max_rel_rms=float(d.max() / rms), rms=rms)
 
 
+def gate_error(q, q_ref, floor=0.1):
+    """The parity gate's error: RAW relative |q - q_ref| / |q_ref| for every score with |q_ref| >= floor * rms(q_ref); scores
+    closer to zero than that (random-init scores cross zero) are measured against rms(q_ref) instead."""
+    q = np.asarray(q, dtype=np.float64)
+    q_ref = np.asarray(q_ref, dtype=np.float64)
+    rms = float(np.sqrt(np.mean(q_ref ** 2)))
+    den = np.where(np.abs(q_ref) >= floor * rms, np.abs(q_ref), rms)
+    return float(np.max(np.abs(q - q_ref) / den))
+
+
 def stress_state(spec, seed, qk=3.0, mlp=3.0, outlier=8.0):
     """Seeded weights with trained-ViT-like statistics instead of the flat random init: query/key scaled so the softmax is
     peaked (mean max-probability 0.5 .. 0.95 instead of 1/S), larger value / MLP gains, and four 'massive activation' channels

@@ -1,5 +1,5 @@
-"""Randomised end-to-end sweep: topology (layers, register tokens, scales, head on/off), batch, patch count, part-batches,
-FR pairs and pairwise triplets drawn from a seeded generator; bf16x3 against the oracle on the host (tools/fuzz_parity.py)."""
+"""Randomised end-to-end sweep: topology (layers, register tokens, scales, head on/off), batch, patch count, numerics mode,
+FR pairs and pairwise triplets drawn from a seeded generator, against the oracle on the host (tools/fuzz_parity.py)."""
 import os
 import subprocess
 import sys

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from vtamiq_amd import _lib
-from tests.gpu_util import stream, to_planes, planes_value
+from tests.gpu_util import FORMATS, elt_dtype, num_code, planes_of, planes_value, stream, to_planes
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -16,88 +16,118 @@ def _randn(*s, seed=0, scale=1.0):
     return (torch.randn(*s, generator=g) * scale).to(DEV)
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
-def test_split_bf16(nsplit):
+FMTS = ["bf16", "bf16x3", "fp16", "fp16x2", "fp16x3"]
+# error of a 16-bit OUTPUT relative to the tensor's max: one plane rounds to 8 / 11 bits, two planes carry 16 / 22
+OUT_TOL = {"bf16": 1e-2, "fp16": 2e-3, "bf16x3": 1e-4, "fp16x2": 2e-5, "fp16x3": 2e-5}
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("role", ["a", "w"])
+def test_split(fmt, role):
     x = _randn(1000, 768, seed=1)
-    p = to_planes(x, nsplit)
-    hi = x.bfloat16()
-    assert torch.equal(p[0], hi)
-    if nsplit == 3:
-        assert torch.equal(p[1], (x - hi.float()).bfloat16())
-        assert (planes_value(p) - x.double()).abs().max() < 2e-5 * x.abs().max()
+    x[0, :8] = torch.tensor([1e-6, -3e-7, 6.1e-5, 0.0, 65000.0 if fmt.startswith("fp16") else 1e30, -1.0, 2.0 ** -24, 1e-8])   # subnormals, range
+    p = to_planes(x, fmt, role)
+    dt = elt_dtype(fmt)
+    hi = x.to(dt)
+    assert p.shape[0] == planes_of(fmt, role) and torch.equal(p[0], hi)
+    if p.shape[0] == 2:
+        assert torch.equal(p[1], (x - hi.float()).to(dt))
+        rel = 2e-5 if dt == torch.bfloat16 else 3e-7
+        assert ((planes_value(p) - x.double()).abs() <= rel * x.abs().double() + 1e-7).all()
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 768), (512, 768, 768), (768, 2304, 768), (256, 768, 3072), (512, 1024, 1024)])
-def test_gemm_bias(nsplit, M, N, K):
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 768), (512, 768, 768), (768, 2304, 768), (256, 768, 3072), (512, 1024, 1024), (2048, 1024, 256)])
+def test_gemm_bias(fmt, M, N, K):
     lib = _lib.load()
     A, W, bias = _randn(M, K, seed=2), _randn(N, K, seed=3, scale=0.05), _randn(N, seed=4)
-    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
-    out = torch.zeros((Ap.shape[0], M, N), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 0, bias.data_ptr(), None, None,
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    out = torch.zeros((Ap.shape[0], M, N), dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), 0, bias.data_ptr(), None, None,
                               out.data_ptr(), M * N, N, stream()))
     torch.cuda.synchronize()
-    if nsplit == 1:
-        ref = Ap[0].double() @ Wp[0].double().t() + bias.double()
-        tol = 1e-2          # output rounded to bf16
-    else:
-        ref = A.double() @ W.double().t() + bias.double()
-        tol = 1e-4
+    ref = planes_value(Ap) @ planes_value(Wp).t() + bias.double()       # the operands as the kernel sees them
+    tol = OUT_TOL[fmt]
     got = planes_value(out)
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
     # asymmetric data + non-square shapes: a transposed or permuted tile would be O(1) wrong
     assert torch.allclose(got, ref, rtol=0, atol=tol * ref.abs().max().item())
+    if FORMATS[fmt][1] == 3:     # the split planes reproduce the fp32 operands: also close to the exact product
+        exact = A.double() @ W.double().t() + bias.double()
+        assert (got - exact).abs().max().item() < (1e-4 if fmt == "bf16x3" else 2e-5) * exact.abs().max().item()
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
-def test_gemm_gelu(nsplit):
+@pytest.mark.parametrize("fmt", FMTS)
+def test_gemm_many_tiles_per_workgroup(fmt):
+    """More than 256 tiles: every workgroup of the persistent launch walks several tiles (DMA ring chained across tile
+    boundaries, half tiles closing the lists); checked on sampled rows against fp64."""
+    lib = _lib.load()
+    M, N, K = 256 * 70, 2304, 768
+    A, W, bias = _randn(M, K, seed=31), _randn(N, K, seed=32, scale=0.05), _randn(N, seed=33)
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    out = torch.zeros((Ap.shape[0], M, N), dtype=elt_dtype(fmt), device=DEV)
+    for _ in range(2):
+        _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), 0, bias.data_ptr(), None, None,
+                                  out.data_ptr(), M * N, N, stream()))
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, M, 97), torch.tensor([127, 128, 255, 256, M - 129, M - 128, M - 1])]).to(DEV)
+    ref = planes_value(Ap)[rows] @ planes_value(Wp).t() + bias.double()
+    got = planes_value(out)[rows]
+    assert (got - ref).abs().max().item() < OUT_TOL[fmt] * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_gemm_gelu(fmt):
     lib = _lib.load()
     M, N, K = 256, 3072, 768
     A, W, bias = _randn(M, K, seed=5), _randn(N, K, seed=6, scale=0.05), _randn(N, seed=7)
-    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
-    out = torch.zeros((Ap.shape[0], M, N), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 1, bias.data_ptr(), None, None,
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    out = torch.zeros((Ap.shape[0], M, N), dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), 1, bias.data_ptr(), None, None,
                               out.data_ptr(), M * N, N, stream()))
     torch.cuda.synchronize()
     pre = (planes_value(Ap) @ planes_value(Wp).t() + bias.double())
     ref = torch.nn.functional.gelu(pre)
     got = planes_value(out)
-    tol = 1e-2 if nsplit == 1 else 1e-4
-    assert (got - ref).abs().max().item() < tol * ref.abs().max().item()
+    assert (got - ref).abs().max().item() < OUT_TOL[fmt] * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("use_gamma", [False, True])
-def test_gemm_residual(nsplit, use_gamma):
+@pytest.mark.parametrize("M", [512, 256 * 41])
+def test_gemm_residual(fmt, use_gamma, M):
     lib = _lib.load()
-    M, N, K = 512, 768, 3072
+    N, K = 768, 3072 if M == 512 else 768
     A, W, bias = _randn(M, K, seed=8), _randn(N, K, seed=9, scale=0.02), _randn(N, seed=10)
     gamma = _randn(N, seed=11) if use_gamma else None
     x0 = _randn(M, N, seed=12)
     x = x0.clone()
-    Ap, Wp = to_planes(A, nsplit), to_planes(W, nsplit)
-    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, nsplit, 2, bias.data_ptr(),
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), 2, bias.data_ptr(),
                               gamma.data_ptr() if use_gamma else None, x.data_ptr(), None, 0, 0, stream()))
     torch.cuda.synchronize()
-    h = planes_value(Ap) @ planes_value(Wp).t() + bias.double()
-    ref = x0.double() + (gamma.double() * h if use_gamma else h)
-    assert (x.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    rows = torch.arange(0, M, 1 if M == 512 else 61, device=DEV)
+    h = planes_value(Ap)[rows] @ planes_value(Wp).t() + bias.double()
+    ref = x0[rows].double() + (gamma.double() * h if use_gamma else h)
+    assert (x[rows].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("fmt", ["bf16", "bf16x3", "fp16", "fp16x3"])
 @pytest.mark.parametrize("H", [768, 1024])
-def test_layernorm(nsplit, H):
+def test_layernorm(fmt, H):
     lib = _lib.load()
     rows = 515
     x = _randn(rows, H, seed=13, scale=3.0) + 0.7
     w, b = _randn(H, seed=14) + 1.0, _randn(H, seed=15)
-    out = torch.zeros((1 if nsplit == 1 else 2, rows, H), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.vtq_k_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), rows * H, rows, H, nsplit, stream()))
+    npl = planes_of(fmt, "a")
+    out = torch.zeros((npl, rows, H), dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), rows * H, rows, H, FORMATS[fmt][0], npl,
+                                   stream()))
     torch.cuda.synchronize()
     ref = torch.nn.functional.layer_norm(x.double(), (H,), w.double(), b.double(), 1e-6)
     got = planes_value(out)
-    tol = 8e-3 if nsplit == 1 else 3e-5
+    tol = {"bf16": 8e-3, "fp16": 1e-3, "bf16x3": 3e-5, "fp16x3": 3e-6}[fmt]
     assert (got - ref).abs().max().item() < tol * ref.abs().max().item()
 
 
@@ -109,11 +139,11 @@ def _attention_ref(qkv, nseq, S, S_pad, H):
     return (p @ v).permute(0, 2, 1, 3).reshape(nseq, S, H)
 
 
-@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("fmt", ["bf16", "bf16x3", "fp16", "fp16x3"])
 @pytest.mark.parametrize("nseq,S,H", [(4, 501, 768), (3, 51, 768), (2, 1025, 1024), (2, 64, 768), (2, 509, 768), (5, 521, 768), (3, 9, 768),
                                       (2, 96, 768)])
 @pytest.mark.parametrize("packed", [True, False])
-def test_attention(nsplit, nseq, S, H, packed):
+def test_attention(fmt, nseq, S, H, packed):
     lib = _lib.load()
     # sequence pitch: the engine packs sequences back to back (pitch = S: the last key tile / query block of a sequence runs
     # into the next one and is masked / not stored); a padded pitch must work as well
@@ -122,14 +152,14 @@ def test_attention(nsplit, nseq, S, H, packed):
     qkv = _randn(rows, 3 * H, seed=16, scale=1.5)
     # a spike so that the running max moves late in the sequence (online-softmax rescale path)
     qkv[S - 3, H:H + 64] *= 6.0
-    P = to_planes(qkv, nsplit)
+    P = to_planes(qkv, fmt, "a")
     npl = P.shape[0]
-    out = torch.zeros((npl, rows, H), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, out.data_ptr(), rows * H, nseq, S, S_pad, H, nsplit, stream()))
+    out = torch.zeros((npl, rows, H), dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, out.data_ptr(), rows * H, nseq, S, S_pad, H, num_code(fmt), stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(planes_value(P)[: nseq * S_pad], nseq, S, S_pad, H)
     got = planes_value(out)[: nseq * S_pad].view(nseq, S_pad, H)[:, :S]
-    tol = 1.5e-2 if nsplit == 1 else 2e-4
+    tol = {"bf16": 1.5e-2, "fp16": 3e-3, "bf16x3": 2e-4, "fp16x3": 1e-5}[fmt]
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
 

@@ -3,13 +3,14 @@
   (b) the oracle run on the host on the same seeded inputs,
 plus size-independent properties at BASELINE.json's full size (B=32, N=500).
 
-Tolerance (BASELINE.json north_star): scores within 1e-3 RELATIVE of the fp32 CPU reference.  The gate applies to
-precision="bf16x3".  Per-element relative error is reported raw; because random-init scores cross zero
-(|q| down to 6e-4 against an rms of ~3e-2) the gate is evaluated with the denominator max(|q_ref|, rms(q_ref)).
-precision="bf16" (single-MFMA throughput mode) is measured against a looser bound that is stated here, not hidden:
-1e-1 (same denominator) -- SURVEY.md section 7 measured 4.5e-2 max relative for bf16 operand rounding on this model with
-random-init weights, and the golden cases here land between 7e-3 and 6e-2.  It is a smoke bound against gross errors,
-NOT a parity claim: only bf16x3 claims the north-star tolerance.
+Tolerance (BASELINE.json north_star): scores within 1e-3 RELATIVE of the fp32 CPU reference.  The gate is the RAW per-score
+relative error |q - q_ref| / |q_ref| wherever |q_ref| >= 0.1 rms(q_ref); random-init scores cross zero (one golden score is 6e-4
+against an rms of 2e-2), and for those near-zero scores the denominator is rms(q_ref) (helpers.gate_error).
+profiles/r02_golden_errors.txt holds the raw table of every case and mode (tools/golden_errors.py).
+Only precision="fp16x3" (the model's default) claims the north-star tolerance: its worst golden case is 4e-5.  The other modes
+are measured against looser bounds that are stated here, not hidden -- smoke bounds against gross errors, NOT parity claims:
+  "bf16x3" 3e-3 (golden cases <= 3.2e-4; the round-1 parity mode, kept: it misses 1e-3 raw on small scores of ViT-L cases),
+  "fp16x2" 5e-3 (weights in single fp16: golden cases <= 2e-3), "fp16" 3e-2 (<= 7.4e-3), "bf16" 1e-1 (<= 7.6e-2).
 """
 import json
 
@@ -18,19 +19,19 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, load_case, rel_err, split_inputs, stress_state
+from tests.helpers import E2E_CASES, gate_error, load_case, rel_err, split_inputs, stress_state
 from vtamiq_amd import VTAMIQ, synth
 from vtamiq_amd.predict import get_data_tuple, predict
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL = {"bf16x3": 1e-3, "bf16": 1e-1}
+TOL = {"fp16x3": 1e-3, "bf16x3": 3e-3, "fp16x2": 5e-3, "fp16": 3e-2, "bf16": 1e-1}
+ALL_MODES = ["fp16x3", "bf16x3", "fp16x2", "fp16", "bf16"]
+MAIN = "fp16x3"          # the default precision of the drop-in model
 
 
 def gate(q, q_ref, tol):
-    q, q_ref = np.asarray(q, np.float64), np.asarray(q_ref, np.float64)
-    rms = np.sqrt(np.mean(q_ref ** 2))
-    return float(np.max(np.abs(q - q_ref) / np.maximum(np.abs(q_ref), rms))) < tol
+    return gate_error(q, q_ref) < tol
 
 
 def build(kw, sd_np, precision):
@@ -39,7 +40,7 @@ def build(kw, sd_np, precision):
     return m.to(DEV).eval()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ALL_MODES)
 @pytest.mark.parametrize("name", E2E_CASES)
 def test_golden(name, precision):
     g, kw, spec, sd, (patches, pos, scales) = load_case(name)
@@ -54,7 +55,7 @@ def test_golden(name, precision):
     assert gate(q.cpu().numpy(), g["q"], TOL[precision]), e
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ALL_MODES)
 def test_token_trace_c1(precision):
     """Per-layer CLS rows (pre final LN) against the reference's return_layers=True capture: localises any divergence."""
     g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
@@ -66,7 +67,7 @@ def test_token_trace_c1(precision):
         model(p, ps, sc, _trace=trace)
     got = trace.cpu().numpy()
     want = np.concatenate([g["tokens_ref"], g["tokens_dist"]], axis=1)       # (L, 2B, T, H)
-    tol = 2e-4 if precision == "bf16x3" else 4e-2
+    tol = {"fp16x3": 2e-5, "fp16x2": 2e-4, "bf16x3": 2e-4, "fp16": 5e-3, "bf16": 4e-2}[precision]
     for layer in range(L):
         d = np.abs(got[layer + 1] - want[layer]).max() / np.abs(want[layer]).max()
         assert d < tol, (layer, d)
@@ -78,7 +79,7 @@ def test_plumbing_c1():
     from tests.helpers import GOLDEN
     g = dict(np.load(os.path.join(GOLDEN, "plumbing_c1.npz")))
     kw = json.loads(str(g["kwargs"]))
-    model = VTAMIQ(**json.loads(json.dumps(kw)), precision="bf16x3")
+    model = VTAMIQ(**json.loads(json.dumps(kw)), precision=MAIN)
     spec = model.spec
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec, int(g["wseed"])).items()})
     model = model.to(DEV).eval()
@@ -101,7 +102,7 @@ def _c2_model(precision):
     return m.to(DEV).eval(), sd
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ALL_MODES)
 def test_full_size_properties(precision):
     """BASELINE config 2 shape (B=32, N=500, ViT-B/16, L=12)."""
     model, sd = _c2_model(precision)
@@ -137,14 +138,14 @@ def test_cls_pruned_last_layer_matches_full_layer(name, monkeypatch):
     g, kw, spec, sd, (patches, pos, scales) = load_case(name)
     p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
     with torch.no_grad():
-        q_pruned = build(kw, sd, "bf16x3")(p, ps, sc)[0].cpu().numpy()
+        q_pruned = build(kw, sd, MAIN)(p, ps, sc)[0].cpu().numpy()
         monkeypatch.setenv("VTQ_NO_CLS_PRUNE", "1")
-        q_full = build(kw, sd, "bf16x3")(p, ps, sc)[0].cpu().numpy()
+        q_full = build(kw, sd, MAIN)(p, ps, sc)[0].cpu().numpy()
     assert gate(q_pruned, g["q"], 1e-3) and gate(q_full, g["q"], 1e-3)
     assert gate(q_pruned, q_full, 3e-4), rel_err(q_pruned, q_full)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x2", "bf16"])
 def test_pairwise_triplets(precision):
     """(ref, dist1, dist2) items.  The fused entry point encodes ref once and must reproduce the two model calls of
     train.py:286-287 bit for bit; predict() then applies the PreferenceModule / sigmoid exactly like train.py:296-301."""
@@ -215,14 +216,13 @@ def test_weight_reload_is_seen():
 
 @pytest.mark.parametrize("B,N,extra,variant,scales", [(1, 8, 0, "ViT-B16", 0), (5, 77, 0, "ViT-B16", 0), (3, 200, 8, "ViT-B16", 0),
                                                       (1, 130, 0, "ViT-L16", 3), (7, 56, 3, "ViT-B16", 2), (2, 119, 8, "ViT-B16", 0)])
-@pytest.mark.parametrize("parts", ["1", "2"])
-def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, parts, monkeypatch):
-    """Edge shapes: B = 1 / odd B (part-batches fall back to one stream), S = N + T hitting 9 / 78 / 209 / 128 exactly (S == S_pad),
-    register tokens, 2- and 3-scale embeddings, ViT-L; oracle on the host as the checker."""
-    monkeypatch.setenv("VTQ_PARTS", parts)
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x2"])
+def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, precision):
+    """Edge shapes: B = 1 / odd B, S = N + T hitting 9 / 78 / 209 / 128 exactly, register tokens, 2- and 3-scale embeddings,
+    ViT-L; oracle on the host as the checker."""
     kw = dict(vit_config=dict(variant=variant, num_keep_layers=2, num_extra_tokens=extra, num_scales=scales, use_layer_scale=bool(extra)),
               num_rgs=2, num_rcabs=2, ca_reduction=16)
-    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="bf16x3")
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
     sd = synth.make_state_dict(m.spec, 40 + B)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.to(DEV).eval()
@@ -233,7 +233,7 @@ def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, parts, monke
     cp, cps, cs = split_inputs(patches, pos, sc)
     q_ref = O.vtamiq_forward(O.to_torch(sd), m.spec, cp, cps, cs)[0].numpy()
     assert q.shape == (B,) and np.isfinite(q).all()
-    assert gate(q, q_ref, 1e-3), rel_err(q, q_ref)
+    assert gate(q, q_ref, TOL[precision]), rel_err(q, q_ref)
 
 
 @pytest.mark.parametrize("qk", [3.0, 5.0, 8.0])
@@ -241,9 +241,10 @@ def test_trained_like_statistics_against_oracle(qk):
     """The flat random init makes attention uniform and activations small, which flatters reduced-precision operands.  Same
     topology (ViT-B/16, all 12 layers) with peaked softmax rows (mean max-probability ~0.6 / ~0.85 / ~0.95) and outlier channels
     of ~30x the stream's rms.  Near one-hot attention makes the MODEL ill-conditioned: the oracle itself moves by `cond` between
-    fp32 and fp64 arithmetic (5e-6 / 2.5e-4 / 5e-4 here), i.e. it amplifies a 6e-8 rounding by up to 1e4.  bf16x3 operands
-    carry 2^-17, so the bound that can be asked of it is max(1e-3, 30 * cond): the north-star 1e-3 wherever the fp32 reference
-    is itself reproducible to ~3e-5, proportionally more where it is not.  The single-MFMA mode's error is printed."""
+    fp32 and fp64 arithmetic (5e-6 / 2.5e-4 / 5e-4 here), i.e. it amplifies a 6e-8 rounding by up to 1e4.  The bound asked of the
+    parity mode (fp16x3, operands to 2^-22) is max(1e-3, 10 * cond): the north-star 1e-3 wherever the fp32 reference is itself
+    reproducible to 1e-4, proportionally more where it is not; bf16x3 (2^-17) gets 30 * cond as in round 1.  The other modes' errors
+    are printed."""
     kw = dict(vit_config=dict(variant="ViT-B16"))
     spec = VTAMIQ(**json.loads(json.dumps(kw))).spec
     sd = stress_state(spec, 5, qk=qk)
@@ -253,14 +254,148 @@ def test_trained_like_statistics_against_oracle(qk):
     q_ref = O.vtamiq_forward(O.to_torch(sd), spec, cp, cps, cs)[0].numpy()
     q_f64 = O.vtamiq_forward(O.to_torch(sd, dtype=torch.float64), spec, [t.double() for t in cp], [t.double() for t in cps], cs)[0].numpy()
     cond = rel_err(q_ref, q_f64)["max_rel_rms"]
-    tol = max(1e-3, 30.0 * cond)
     errs = {}
-    for precision in ("bf16x3", "bf16"):
+    for precision in ALL_MODES:
         m = build(kw, sd, precision)
         with torch.no_grad():
             q = m(p, ps, s3)[0].cpu().numpy()
         assert np.isfinite(q).all()
         errs[precision] = rel_err(q, q_ref)["max_rel_rms"]
-        if precision == "bf16x3":
-            assert gate(q, q_ref, tol), (q, q_ref, errs, cond)
-    print("trained-like statistics qk=%g: oracle fp32-vs-fp64 %.1e, tolerance %.1e, errors %s" % (qk, cond, tol, errs))
+        if precision in ("fp16x3", "bf16x3"):
+            tol = max(1e-3, (10.0 if precision == "fp16x3" else 30.0) * cond)
+            assert rel_err(q, q_ref)["max_rel_rms"] < tol, (q, q_ref, errs, cond)
+    print("trained-like statistics qk=%g: oracle fp32-vs-fp64 %.1e, errors %s" % (qk, cond, errs))
+
+
+# ---- evidence for the configurations and rows the golden fixtures only cover at reduced size ------------------------------
+
+def test_config4_full_size_vit_l():
+    """BASELINE configs[3] at FULL size: ViT-L/16 (H=1024, L=24, 16 heads), B=16 pairs, N=1024 patches over 3 scales (S=1025:
+    17 key tiles, 9 query blocks per sequence).  Batch invariance (bitwise), determinism, and one pair against the oracle."""
+    kw = dict(vit_config=dict(variant="ViT-L16", num_scales=3))
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=MAIN)
+    spec = m.spec
+    assert (spec.hidden_size, spec.num_layers, spec.num_heads, spec.mlp_dim) == (1024, 24, 16, 4096)
+    sd = synth.make_state_dict(spec, 77)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    B, N = 16, 1024
+    patches, pos, sc = synth.make_inputs(spec, B, N, 78)
+    assert sc is not None and set(np.unique(sc)) == {0, 1, 2}
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    with torch.no_grad():
+        q = m(p, ps, s3)[0]
+        sel = [0, 7, 15]
+        q_small = m(tuple(t[sel].contiguous() for t in p), tuple(t[sel].contiguous() for t in ps), tuple(t[sel].contiguous() for t in s3))[0]
+        assert torch.equal(q[sel], q_small)
+        assert torch.equal(q, m(p, ps, s3)[0])
+    assert q.shape == (B,) and bool(torch.isfinite(q).all())
+    one = [7]
+    cp, cps, cs = split_inputs(patches[one], pos[one], sc[one])
+    torch.set_num_threads(16)
+    q_ref = O.vtamiq_forward(O.to_torch(sd), spec, cp, cps, cs)[0].numpy()
+    e = rel_err(q[one].cpu().numpy(), q_ref)
+    print(f"\n[configs[3] full size, {MAIN}] q={q[one].cpu().numpy()} ref={q_ref} {e}")
+    assert e["max_rel"] < 1e-3, e
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x2"])
+def test_long_sequence_beyond_2048_tokens(precision):
+    """N = 2500 patches per image (the reference's README advertises up to 5000): S = 2501 goes through the CLS-pruned last layer
+    with its score buffer in dynamic LDS (round 1 failed for S > 2048).  2 layers keep the host-side oracle affordable."""
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=2))
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+    sd = synth.make_state_dict(m.spec, 91)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    patches, pos, sc = synth.make_inputs(m.spec, 2, 2500, 92)
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    with torch.no_grad():
+        q = m(p, ps, s3)[0].cpu().numpy()
+    cp, cps, cs = split_inputs(patches, pos, sc)
+    q_ref = O.vtamiq_forward(O.to_torch(sd), m.spec, cp, cps, cs)[0].numpy()
+    assert gate(q, q_ref, TOL[precision]), rel_err(q, q_ref)
+
+
+def test_ingested_npz_weights_through_the_engine(tmp_path):
+    """SURVEY 8f-3 on the GPU: a JAX-layout ViT-B/16 .npz (synthetic, seeded; 14x14 position grid so the bilinear resize to 24x24
+    runs) -> weights.load_vit_npz -> engine scores, against the oracle on the state dict the (CPU-pinned) converter returns."""
+    from vtamiq_amd import weights as W
+    L = 2
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=L, pretrained=False), num_rgs=1, num_rcabs=2)
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=MAIN)
+    rs = np.random.RandomState(11)
+    H, M, P = 768, 3072, 16
+    n = lambda *s: (0.02 * rs.randn(*s)).astype(np.float32)
+    w = {"embedding/kernel": n(P, P, 3, H), "embedding/bias": n(H), "cls": n(1, 1, H),
+         "Transformer/posembed_input/pos_embedding": n(1, 14 * 14 + 1, H), "Transformer/encoder_norm/scale": 1 + n(H),
+         "Transformer/encoder_norm/bias": n(H)}
+    for i in range(L):
+        r = f"Transformer/encoderblock_{i}"
+        for nm in ("query", "key", "value"):
+            w[f"{r}/MultiHeadDotProductAttention_1/{nm}/kernel"] = n(H, 12, 64)
+            w[f"{r}/MultiHeadDotProductAttention_1/{nm}/bias"] = n(12, 64)
+        w[f"{r}/MultiHeadDotProductAttention_1/out/kernel"] = n(12, 64, H)
+        w[f"{r}/MultiHeadDotProductAttention_1/out/bias"] = n(H)
+        w[f"{r}/MlpBlock_3/Dense_0/kernel"] = n(H, M); w[f"{r}/MlpBlock_3/Dense_0/bias"] = n(M)
+        w[f"{r}/MlpBlock_3/Dense_1/kernel"] = n(M, H); w[f"{r}/MlpBlock_3/Dense_1/bias"] = n(H)
+        for ln in ("LayerNorm_0", "LayerNorm_2"):
+            w[f"{r}/{ln}/scale"] = 1 + n(H); w[f"{r}/{ln}/bias"] = n(H)
+    path = tmp_path / "vit_b16.npz"
+    np.savez(path, **w)
+    m = m.to(DEV).eval()
+    patches, pos, sc = synth.make_inputs(m.spec, 3, 40, 12)
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    with torch.no_grad():
+        q_before = m(p, ps, s3)[0].clone()         # packs the constructor's random weights first: the reload must be seen
+        W.load_vit_npz(m, str(path))
+        q = m(p, ps, s3)[0].cpu().numpy()
+    assert not np.allclose(q, q_before.cpu().numpy())
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    conv = W.convert_vit_npz(w, H, L, 577)
+    for k, v in conv.items():
+        assert torch.equal(sd[k].reshape(v.shape), v), k
+    cp, cps, cs = split_inputs(patches, pos, sc)
+    q_ref = O.vtamiq_forward(sd, m.spec, cp, cps, cs)[0].numpy()
+    assert gate(q, q_ref, 1e-3), rel_err(q, q_ref)
+
+
+def test_position_out_of_range_is_clamped_and_reported():
+    """pos == 1.0, pos < 0 and NaN index outside the 577-row table in the reference (IndexError / device assert,
+    transformer.py:417-421).  The engine clamps the index (finite scores, no out-of-bounds gather) and reports it."""
+    model, _ = _c2_model("fp16")
+    spec = model.spec
+    patches, pos, _ = synth.make_inputs(spec, 2, 24, 3)
+    p, ps, sc = split_inputs(patches, pos, None, device=DEV)
+    with torch.no_grad():
+        q_ok = model(p, ps, sc)[0]
+        model.check_inputs()                                   # in range: no error
+        bad = ps[0].clone()
+        bad[0, 0, 0] = 1.0
+        bad[0, 1, 1] = -0.25
+        bad[1, 2, 0] = float("nan")
+        q_bad = model(p, (bad, ps[1]), sc)[0]
+        assert bool(torch.isfinite(q_bad).all())
+        with pytest.raises(IndexError):
+            model.check_inputs()
+        model.check_inputs()                                   # the flag was cleared by the read
+        model.validate_inputs = True
+        with pytest.raises(IndexError):
+            model(p, (bad, ps[1]), sc)
+        model.validate_inputs = False
+        assert torch.equal(model(p, ps, sc)[0], q_ok)
+
+
+def test_patch_sample_range_is_checked():
+    from vtamiq_amd.patches import extract_patches
+    img = torch.zeros(1, 64, 80, 3, dtype=torch.uint8, device=DEV)
+    ok = torch.tensor([[[0, 0], [48, 64]]], dtype=torch.int32)
+    extract_patches(img, ok)
+    for bad in ([[49, 0]], [[0, 65]], [[-1, 0]]):
+        with pytest.raises(IndexError):
+            extract_patches(img, torch.tensor([bad], dtype=torch.int32))
+    with pytest.raises(IndexError):
+        extract_patches(img, ok, scale_ids=torch.tensor([[0, 2]], dtype=torch.int32), num_scales=2)
+    with pytest.raises(ValueError):
+        extract_patches(torch.zeros(1, 24, 24, 3, dtype=torch.uint8, device=DEV), torch.zeros(1, 1, 2, dtype=torch.int32), num_scales=2,
+                        scale_ids=torch.zeros(1, 1, dtype=torch.int32))

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.vtq_abi_version.restype = ctypes.c_int
-    assert lib.vtq_abi_version() == 1
+    assert lib.vtq_abi_version() == _lib.ABI_VERSION
 
 
 def test_config_struct_matches_header():
@@ -124,26 +124,44 @@ def test_predict_pairwise_branch_matches_reference_semantics():
 
 
 def test_gemm_tile_schedule_covers_every_tile_once():
-    """The host-built block order of the GEMM (gemm.hip build_schedule): every 256x256 tile appears exactly once, either whole
-    or as its top AND bottom half; pure host code, callable without a GPU."""
+    """The host-built persistent schedule of the GEMM (gemm.hip build_schedule): 256 per-workgroup lists; every 256x256 tile
+    appears exactly once, either whole or as its top AND bottom half; half tiles only close a list; lists are balanced; pure
+    host code, callable without a GPU."""
     import ctypes as C
     import numpy as np
     from vtamiq_amd import _lib
     lib = _lib.load()
-    assert lib.vtq_k_gemm_schedule(100, 256, None, 0) == -1
-    for M, N in [(256, 256), (1024, 768), (16384, 768), (16384, 2304), (16384, 3072), (32768, 2304), (32768, 768), (33024, 1024),
-                 (65536, 4096)]:
-        n = lib.vtq_k_gemm_schedule(M, N, None, 0)
+    assert lib.vtq_k_gemm_schedule(100, 256, 768, 1, None, 0) == -1
+    for M, N, K, wpl in [(256, 256, 768, 1), (1024, 768, 768, 2), (16384, 768, 3072, 2), (16384, 2304, 768, 1), (16384, 3072, 768, 2),
+                         (32256, 3072, 768, 1), (32768, 2304, 768, 2), (32768, 768, 768, 1), (33024, 1024, 4096, 2), (65536, 4096, 1024, 1)]:
+        n = lib.vtq_k_gemm_schedule(M, N, K, wpl, None, 0)
         out = np.full(n, -1, np.int32)
-        assert lib.vtq_k_gemm_schedule(M, N, out.ctypes.data_as(C.c_void_p), n) == n
+        assert lib.vtq_k_gemm_schedule(M, N, K, wpl, out.ctypes.data_as(C.c_void_p), n) == n
+        nwg = 256
+        offs, ent = out[: nwg + 1], out[nwg + 1:]
+        assert offs[0] == nwg + 1 and offs[nwg] == n and (np.diff(offs) >= 0).all()
         nt = (M // 256) * (N // 256)
-        tile, kind = out >> 2, out & 3
+        tile, kind = ent >> 2, ent & 3
         assert tile.min() >= 0 and tile.max() < nt and kind.max() <= 2
         whole = np.bincount(tile[kind == 0], minlength=nt)
         top = np.bincount(tile[kind == 1], minlength=nt)
         bot = np.bincount(tile[kind == 2], minlength=nt)
         assert ((whole == 1) & (top == 0) & (bot == 0) | (whole == 0) & (top == 1) & (bot == 1)).all(), (M, N)
-        assert n == nt + int((kind == 1).sum())
+        assert len(ent) == nt + int((kind == 1).sum())
+        loads = []
+        for b in range(nwg):
+            k = out[offs[b]:offs[b + 1]] & 3
+            if len(k):
+                first_half = np.argmax(k != 0) if (k != 0).any() else len(k)
+                assert (k[first_half:] != 0).all(), "a whole tile after a half tile"
+            loads.append(float((k == 0).sum() + 0.57 * (k != 0).sum()))
+        assert max(loads) - min(loads) <= 1.0 + 1e-9, (M, N, min(loads), max(loads))
+        # workgroup b runs on XCD b % 8: the XCD owns a contiguous run of the row-major tile order
+        for x in range(8):
+            mine = np.concatenate([out[offs[b]:offs[b + 1]] >> 2 for b in range(x, nwg, 8)])
+            if len(mine):
+                u = np.unique(mine)
+                assert u.max() - u.min() + 1 == len(u)
 
 
 def test_abi_rejects_bad_arguments_without_touching_a_gpu():
@@ -174,4 +192,4 @@ def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     assert lib.vtq_load_weights(None, None, 0, None) != 0
     assert lib.vtq_reserve(None, 1, 1) != 0
     assert lib.vtq_workspace_bytes(None, 1, 1) == 0
-    assert lib.vtq_k_gemm_schedule(256, 100, None, 0) == -1
+    assert lib.vtq_k_gemm_schedule(256, 100, 768, 1, None, 0) == -1

@@ -4,23 +4,23 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vtamiq_amd import _lib
-from tests.gpu_util import to_planes, planes_value, stream
+from tests.gpu_util import elt_dtype, num_code, to_planes, planes_value, stream
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nseq", type=int, default=64)
 ap.add_argument("--S", type=int, default=501)
 ap.add_argument("--H", type=int, default=768)
-ap.add_argument("--nsplit", type=int, nargs="+", default=[1, 3])
+ap.add_argument("--fmt", nargs="+", default=["bf16", "bf16x3", "fp16", "fp16x3"])
 a = ap.parse_args()
 lib = _lib.load()
-S_pad = (a.S + 63) // 64 * 64
+S_pad = a.S          # the engine packs sequences back to back
 rows = a.nseq * S_pad + 128
 g = torch.Generator(device="cpu").manual_seed(0)
 qkv = (torch.randn(rows, 3 * a.H, generator=g) * 1.5).cuda()
-for ns in a.nsplit:
-    P = to_planes(qkv, ns)
-    out = torch.zeros((P.shape[0], rows, a.H), dtype=torch.bfloat16, device="cuda")
-    call = lambda: _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * a.H, out.data_ptr(), rows * a.H, a.nseq, a.S, S_pad, a.H, ns, stream()))
+for fmt in a.fmt:
+    P = to_planes(qkv, fmt, "a")
+    out = torch.zeros((P.shape[0], rows, a.H), dtype=elt_dtype(fmt), device="cuda")
+    call = lambda: _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * a.H, out.data_ptr(), rows * a.H, a.nseq, a.S, S_pad, a.H, num_code(fmt), stream()))
     call(); torch.cuda.synchronize()
     nh = a.H // 64
     x = planes_value(P)[: 2 * S_pad].view(2, S_pad, 3, nh, 64)[:, :a.S]
@@ -38,4 +38,4 @@ for ns in a.nsplit:
         ts.append(e0.elapsed_time(e1) / 5)
     ts.sort()
     fl = 4.0 * a.nseq * nh * a.S * a.S * 64
-    print(f"attention ns={ns} nseq={a.nseq} S={a.S} H={a.H}: {ts[3]*1e3:.1f} us  {fl/ts[3]/1e9:.1f} TF algorithmic  err {err:.1e}")
+    print(f"attention {fmt} nseq={a.nseq} S={a.S} H={a.H}: {ts[3]*1e3:.1f} us  {fl/ts[3]/1e9:.1f} TF algorithmic  err {err:.1e}")

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel-class time of one forward (HIP events on the launch streams) for the bench workload.
-   VTQ_PARTS=1 serialises the launches so the classes add up to the step."""
+"""Per-kernel-class time of one forward (HIP events on the launch stream) for the bench workload."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +8,7 @@ from vtamiq_amd import VTAMIQ, synth, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--patches", type=int, default=500)
 ap.add_argument("--refdefault", action="store_true")
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["bf16x3", "bf16"])
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16"])
 a = ap.parse_args()
 for prec in a.precision:
     m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True),
@@ -29,7 +28,7 @@ for prec in a.precision:
         prof = m.profile_collect()
     ms = [prof[k][0] for k in _lib.KERNEL_CLASSES]; n = [prof[k][1] for k in _lib.KERNEL_CLASSES]
     tot = sum(ms) / a.steps
-    print(f"{prec} parts={os.environ.get('VTQ_PARTS', '2')} B={a.batch} N={a.patches}: {dt*1e3:.2f} ms/step unprofiled; classes sum {tot:.2f} ms")
+    print(f"{prec} B={a.batch} N={a.patches}: {dt*1e3:.2f} ms/step unprofiled; classes sum {tot:.2f} ms")
     for k, name in enumerate(_lib.KERNEL_CLASSES):
         if n[k]:
             print(f"   {name:12s} {ms[k]/a.steps:7.3f} ms/step  {n[k]//a.steps:3d} launches  {ms[k]/n[k]*1e3:8.1f} us/launch")

@@ -10,6 +10,15 @@ LIB_PATH = os.environ.get("VTQ_LIB_PATH") or os.path.join(_HERE, "libvtamiq_hip.
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
+PREC_FP16 = 2
+PREC_FP16X3 = 3
+PREC_FP16X2 = 4
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3, "fp16x2": PREC_FP16X2}
+# operand-format codes of the per-kernel entry points (VTQ_NUM_*): MFMAs per product + 16 for fp16 planes
+NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19}
+# MFMAs per product of the linear layers / of attention, per precision (bench.py)
+MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3)}
+ABI_VERSION = 2
 
 KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]
 
@@ -40,12 +49,13 @@ SIGNATURES = {
     "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "vtq_k_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "vtq_k_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                              C.c_void_p]),
     "vtq_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                  C.c_int32, C.c_void_p]),
+                                  C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_small_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_image_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), C.c_void_p]),
@@ -54,7 +64,7 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_repeat_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_rank_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "vtq_k_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "vtq_k_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
 }
@@ -79,7 +89,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.vtq_abi_version() != 1:
+    if lib.vtq_abi_version() != ABI_VERSION:
         raise RuntimeError("libvtamiq_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -13,8 +13,11 @@
 //     lane movement; V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
 //   * K tile chunks are XOR-swizzled ((row>>1)&7) for conflict-free ds_read_b128; V tile 64-byte halves are swapped on
 //     rows with bit 1 set so the four rows of a transposed read hit disjoint banks;
-//   * NSPLIT == 3: Q,K,V,P are hi/lo bf16 pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
+//   * NSPLIT == 3: Q,K,V,P are hi/lo 16-bit pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
+//   * T = bf16 | f16 operand planes.  P (in (0, 1]) is split with a TRUNCATED hi part, so that lo = v - hi is exact in fp32 and
+//     costs one subtract and half a packed convert: f16: v_cvt_pkrtz + v_fma_mix per element; bf16: mask + subtract.
 #include <cstdlib>
+#include <mutex>
 
 #include "dev_common.h"
 #include "kernels.h"
@@ -22,13 +25,45 @@
 namespace vtq {
 namespace {
 
-__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, int64_t plane, bf16* __restrict__ out,
+// Split 8 probabilities into the hi / lo MFMA fragments (element j of the fragment = p[j]).
+template <typename T>
+__device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x8& hi, typename Vec<T>::x8& lo) {
+    if constexpr (std::is_same<T, f16>::value) {
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]);      // truncation: hi <= p, p - hi exact
+            hw[j] = __builtin_bit_cast(uint32_t, hp);
+            float r0, r1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw[j]), "v"(p[2 * j]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw[j]), "v"(p[2 * j + 1]));
+            lw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        }
+        typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+        hi = __builtin_bit_cast(f16x8, u4{hw[0], hw[1], hw[2], hw[3]});
+        lo = __builtin_bit_cast(f16x8, u4{lw[0], lw[1], lw[2], lw[3]});
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t hb = __builtin_bit_cast(uint32_t, p[j]) & 0xFFFF0000u;     // bf16 by truncation
+            const float hf = __builtin_bit_cast(float, hb);
+            hi[j] = __builtin_bit_cast(bf16, (unsigned short)(hb >> 16));
+            lo[j] = (bf16)(p[j] - hf);
+        }
+    }
+}
+
+template <typename T, int NSPLIT>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out,
                                                         int64_t o_plane, int S, int S_pad, int H) {
+    typedef typename Vec<T>::x8 tx8;
+    typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
     constexpr int KT = 64, KB = KT / 32;     // 64-key K/V tiles = two 32-key blocks; two LDS buffers (3-deep rings and 32-key tiles: no gain)
     constexpr int TB = KT * 128;             // one KT-key x 64-dim bf16 tile
@@ -55,12 +90,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const int q_row = qb * 128 + wave * 32 + c;
 
     // ---- Q fragments: B operand of S^T = K Q^T, element j <-> d = 16t + 8hh + j ------------------------------
-    bf16x8 qf[NPL][4];
+    tx8 qf[NPL][4];
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            qf[pl][t] = *(const bf16x8*)(qkv + pl * plane + (row0 + q_row) * ld + head * 64 + 16 * t + 8 * hh);
+            qf[pl][t] = *(const tx8*)(qkv + pl * plane + (row0 + q_row) * ld + head * 64 + 16 * t + 8 * hh);
 
     // ---- DMA source offsets (elements) of this thread for the two rounds of a 64-row tile --------------------
     uint32_t k_off[KB], v_off[KB];
@@ -73,7 +108,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     }
     auto stage = [&](int t, int buf) {
         char* sb = smem + buf * STAGE + wave * 1024;
-        const bf16* base = qkv + (row0 + (int64_t)t * KT) * ld;
+        const T* base = qkv + (row0 + (int64_t)t * KT) * ld;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -119,12 +154,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int off = kb * 32 * 128 + k_rd + (((2 * tt + hh) ^ k_sw) << 4);
-                const bf16x8 kf = *(const bf16x8*)(sk + off);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][tt], tt == 0 ? zero16 : sacc[kb], 0, 0, 0);
+                const tx8 kf = *(const tx8*)(sk + off);
+                sacc[kb] = mfma32<T>(kf, qf[0][tt], tt == 0 ? zero16 : sacc[kb]);
                 if constexpr (NSPLIT == 3) {
-                    const bf16x8 kl = *(const bf16x8*)(sk + TB + off);
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][tt], sacc[kb], 0, 0, 0);
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][tt], sacc[kb], 0, 0, 0);
+                    const tx8 kl = *(const tx8*)(sk + TB + off);
+                    sacc[kb] = mfma32<T>(kf, qf[1][tt], sacc[kb]);
+                    sacc[kb] = mfma32<T>(kl, qf[0][tt], sacc[kb]);
                 }
             }
         }
@@ -146,7 +181,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                                              // raw (unscaled) running max
-        const float nm = -m_new * sc;
+        // f16 planes: P is kept as 2^12 * exp(s - m) in (0, 4096], so that the lo half of its split (2^-11 of the value) stays a
+        // NORMAL f16 down to p = 3e-5 of the row maximum (v_cvt_pkrtz_f16_f32 flushes subnormal results); the row sum carries
+        // the same factor and it cancels in O / l.
+        constexpr float kPExp = std::is_same<T, f16>::value ? 12.0f : 0.0f;
+        const float nm = kPExp - m_new * sc;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -172,28 +211,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 ph, pl_;
+                tx8 ph, pl_;
+                if constexpr (NSPLIT == 1) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = sacc[kb][8 * s2 + j];
-                    if constexpr (NSPLIT == 1) ph[j] = (bf16)pv;
-                    else { bf16 a, b; split2(pv, a, b); ph[j] = a; pl_[j] = b; }
+                    for (int j = 0; j < 8; ++j) ph[j] = (T)sacc[kb][8 * s2 + j];
+                } else {
+                    float pj[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pj[j] = sacc[kb][8 * s2 + j];
+                    split_p8<T>(pj, ph, pl_);
                 }
                 const int vrow = kb * 32 + 16 * s2 + v_row;
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     // byte column of (d-block, 16-column half, 4-column piece); bit 6 carries the row swizzle
                     const char* a0 = sv + vrow * 128 + (v_colb ^ (d << 6));
-                    const bf16x4 v0 = lds_tr16(a0);
-                    const bf16x4 v1 = lds_tr16(a0 + 8 * 128);
-                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, o_acc[d], 0, 0, 0);
+                    const s16x4 v0 = lds_tr16(a0);
+                    const s16x4 v1 = lds_tr16(a0 + 8 * 128);
+                    const tx8 vf = __builtin_bit_cast(tx8, s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+                    o_acc[d] = mfma32<T>(vf, ph, o_acc[d]);
                     if constexpr (NSPLIT == 3) {
-                        const bf16x4 w0 = lds_tr16(a0 + TB);
-                        const bf16x4 w1 = lds_tr16(a0 + TB + 8 * 128);
-                        const bf16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pl_, o_acc[d], 0, 0, 0);
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o_acc[d], 0, 0, 0);
+                        const s16x4 w0 = lds_tr16(a0 + TB);
+                        const s16x4 w1 = lds_tr16(a0 + TB + 8 * 128);
+                        const tx8 vl = __builtin_bit_cast(tx8, s16x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]});
+                        o_acc[d] = mfma32<T>(vf, pl_, o_acc[d]);
+                        o_acc[d] = mfma32<T>(vl, ph, o_acc[d]);
                     }
                 }
             }
@@ -207,7 +249,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_row < S_pad) {
-        bf16* o = out + (row0 + q_row) * H + head * 64;
+        T* o = out + (row0 + q_row) * H + head * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -217,14 +259,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
                 if constexpr (NSPLIT == 1) {
-                    bf16x4 hv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *(bf16x4*)(o + dcol) = hv;
+                    tx4 hv = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                    *(tx4*)(o + dcol) = hv;
                 } else {
-                    bf16x4 hv, lv;
+                    tx4 hv, lv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bf16 a, b; split2(v[e], a, b); hv[e] = a; lv[e] = b; }
-                    *(bf16x4*)(o + dcol) = hv;
-                    *(bf16x4*)(o + o_plane + dcol) = lv;
+                    for (int e = 0; e < 4; ++e) { T a, b; split2<T>(v[e], a, b); hv[e] = a; lv[e] = b; }
+                    *(tx4*)(o + dcol) = hv;
+                    *(tx4*)(o + o_plane + dcol) = lv;
                 }
             }
     }
@@ -232,25 +274,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
 }  // namespace
 
-template <int NSPLIT>
+template <typename T, int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s) {
     constexpr int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
+    static std::mutex mu;
+    static bool configured[64] = {false};          // hipFuncSetAttribute is per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            e = hipFuncSetAttribute((const void*)attention_kernel<T, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
     }
     const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
-    hipLaunchKernelGGL((attention_kernel<NSPLIT>), grid, blk, LDS, s, (const bf16*)qkv, plane, (bf16*)out, o_plane, S, S_pad, H);
+    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            int nsplit, hipStream_t s) {
-    if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-    if (nsplit == 1) return launch_attention_t<1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
-    return launch_attention_t<3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+                            Num num, hipStream_t s) {
+    if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (num.terms != 1 && num.terms != 3)) return hipErrorInvalidValue;
+    if (!num.f16) {
+        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    }
+    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
+    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s);
 }
 
 }  // namespace vtq

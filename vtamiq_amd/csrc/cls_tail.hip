@@ -3,8 +3,10 @@
 // VTAMIQ consumes token 0 of the encoder output and nothing else (modules/vtamiq/vtamiq.py:104-108), so in the LAST
 // EncoderLayer (modules/VisionTransformer/transformer.py:275-285) only the K/V projections need every row; the query,
 // the attention output, out-proj, LayerNorm_2 and the MLP are needed for the 2B CLS rows alone.  These kernels run that
-// 2B-row tail in fp32 activations against the packed bf16 (hi[, lo]) weight planes; results are identical in exact
+// 2B-row tail in fp32 activations against the packed 16-bit (hi[, lo]) weight planes; results are identical in exact
 // arithmetic to running the full layer and reading row 0 (SURVEY.md 8d allows the pruning; bench reports executed flops).
+#include <mutex>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -48,8 +50,8 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
 enum { ROWS_PLAIN = 0, ROWS_GELU = 1, ROWS_RESID = 2 };
 
 // y[r][n] = epi(sum_k (w_hi[n][k] + w_lo[n][k]) * x[r][k] + bias[n]);  K % 256 == 0; one wave = one n x 8 rows.
-template <int NPL, int EPI>
-__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, const bf16* __restrict__ W, int64_t w_plane,
+template <typename T, int NPL, int EPI>
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, const T* __restrict__ W, int64_t w_plane,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
                                                           const float* __restrict__ res, float* __restrict__ y, int R, int N, int K) {
     const int lane = threadIdx.x & 63;
@@ -57,14 +59,15 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restric
     if (n >= N) return;
     const int r0 = blockIdx.y * 8;
     const int KP = K >> 8;                        // 4-element pieces per lane
-    const bf16* wr = W + (int64_t)n * K;
+    typedef typename Vec<T>::x4 tx4;
+    const T* wr = W + (int64_t)n * K;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int pc = 0; pc < KP; ++pc) {
         const int idx = pc * 64 + lane;           // float4 index inside the row
-        const bf16x4 wh = ((const bf16x4*)wr)[idx];
+        const tx4 wh = ((const tx4*)wr)[idx];
         float4 w4 = {(float)wh[0], (float)wh[1], (float)wh[2], (float)wh[3]};
         if constexpr (NPL == 2) {
-            const bf16x4 wl = ((const bf16x4*)(wr + w_plane))[idx];
+            const tx4 wl = ((const tx4*)(wr + w_plane))[idx];
             w4.x += (float)wl[0]; w4.y += (float)wl[1]; w4.z += (float)wl[2]; w4.w += (float)wl[3];
         }
 #pragma unroll
@@ -94,17 +97,19 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restric
 // attention of the single CLS query of each (sequence, head) over the S keys of the sequence; K, V from the packed bf16 planes.
 // One 4-wave workgroup per (sequence, head): thread t scores keys t, t+256, ...; wave w accumulates the keys = w (mod 4)
 // of the PV sum, four keys in flight per iteration; partial maxima / sums / outputs meet in LDS.
-template <int NPL>
-__global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ q, const bf16* __restrict__ qkv, int64_t plane,
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ q, const T* __restrict__ qkv, int64_t plane,
                                                             float* __restrict__ out, int S, int S_pad, int H) {
-    __shared__ float ps[2048];
-    __shared__ float red[8];
-    __shared__ float part[4][64];
+    typedef typename Vec<T>::x8 tx8;
+    extern __shared__ __attribute__((aligned(16))) float cls_smem[];     // [8] red | [4][64] part | [S] scores
+    float* red = cls_smem;
+    float (*part)[64] = (float (*)[64])(cls_smem + 8);
+    float* ps = cls_smem + 8 + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, seq = blockIdx.y;
     const int ld = 3 * H;
-    const bf16* kb = qkv + ((int64_t)seq * S_pad) * ld + H + head * 64;
-    const bf16* vb = kb + H;
+    const T* kb = qkv + ((int64_t)seq * S_pad) * ld + H + head * 64;
+    const T* vb = kb + H;
     float qv[64];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -113,13 +118,13 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
     }
     float mx = -INFINITY;
     for (int key = tid; key < S; key += 256) {
-        const bf16* kr = kb + (int64_t)key * ld;
+        const T* kr = kb + (int64_t)key * ld;
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const bf16x8 kh = ((const bf16x8*)kr)[c];
-            bf16x8 kl;
-            if constexpr (NPL == 2) kl = ((const bf16x8*)(kr + plane))[c];
+            const tx8 kh = ((const tx8*)kr)[c];
+            tx8 kl;
+            if constexpr (NPL == 2) kl = ((const tx8*)(kr + plane))[c];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float kv = (float)kh[e];
@@ -175,24 +180,54 @@ hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, cons
     return hipGetLastError();
 }
 
-hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int nsplit, const float* bias, const float* gamma,
+hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int f16_, int wplanes, const float* bias, const float* gamma,
                               const float* res, float* y, int R, int N, int K, int epi, hipStream_t s) {
-    if (K % 256 || epi < 0 || epi > 2) return hipErrorInvalidValue;
+    if (K % 256 || epi < 0 || epi > 2 || (wplanes != 1 && wplanes != 2)) return hipErrorInvalidValue;
     const dim3 g((N + 3) / 4, (R + 7) / 8), blk(256);
-#define VTQ_RL(NP, EP) hipLaunchKernelGGL((rows_linear_kernel<NP, EP>), g, blk, 0, s, x, (const bf16*)W, w_plane, bias, gamma, res, y, R, N, K)
-    if (nsplit == 1) { if (epi == 0) VTQ_RL(1, 0); else if (epi == 1) VTQ_RL(1, 1); else VTQ_RL(1, 2); }
-    else { if (epi == 0) VTQ_RL(2, 0); else if (epi == 1) VTQ_RL(2, 1); else VTQ_RL(2, 2); }
+#define VTQ_RL(TT, NP, EP) hipLaunchKernelGGL((rows_linear_kernel<TT, NP, EP>), g, blk, 0, s, x, (const TT*)W, w_plane, bias, gamma, res, y, R, N, K)
+#define VTQ_RL_E(TT, NP) do { if (epi == 0) VTQ_RL(TT, NP, 0); else if (epi == 1) VTQ_RL(TT, NP, 1); else VTQ_RL(TT, NP, 2); } while (0)
+    if (!f16_) { if (wplanes == 1) VTQ_RL_E(bf16, 1); else VTQ_RL_E(bf16, 2); }
+    else { if (wplanes == 1) VTQ_RL_E(f16, 1); else VTQ_RL_E(f16, 2); }
+#undef VTQ_RL_E
 #undef VTQ_RL
     return hipGetLastError();
 }
 
-hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int nsplit, hipStream_t s) {
-    if (S > 2048) return hipErrorInvalidValue;
-    const dim3 g(H / 64, nseq), blk(256);
-    if (nsplit == 1) hipLaunchKernelGGL(cls_attention_kernel<1>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
-    else hipLaunchKernelGGL(cls_attention_kernel<2>, g, blk, 0, s, q, (const bf16*)qkv, plane, out, S, S_pad, H);
+namespace {
+constexpr int kClsLdsMax = 160 * 1024 - 4096;                 // leave room for the runtime's own LDS use
+constexpr int kClsFixed = (8 + 256) * 4;
+template <typename T, int NPL>
+hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
+                                  hipStream_t s) {
+    const int lds = kClsFixed + ((S + 3) & ~3) * 4;
+    if (lds > 48 * 1024) {                                    // beyond the default limit: raise it once per device
+        static std::mutex mu;
+        static bool configured[64] = {false};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            e = hipFuncSetAttribute((const void*)cls_attention_kernel<T, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, kClsLdsMax);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((cls_attention_kernel<T, NPL>), dim3(H / 64, nseq), dim3(256), lds, s, q, (const T*)qkv, plane, out, S, S_pad, H);
     return hipGetLastError();
+}
+}  // namespace
+
+int cls_attention_max_seq() { return (kClsLdsMax - kClsFixed) / 4; }
+
+hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
+                                int f16_, int planes, hipStream_t s) {
+    if (S < 1 || S > cls_attention_max_seq() || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
+    if (!f16_) return planes == 1 ? launch_cls_attention_t<bf16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, s)
+                                  : launch_cls_attention_t<bf16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, s);
+    return planes == 1 ? launch_cls_attention_t<f16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, s)
+                       : launch_cls_attention_t<f16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, s);
 }
 
 }  // namespace vtq

@@ -1,4 +1,5 @@
-// HBM-bound kernels of the ViT path: fp32 -> bf16(hi,lo) packing, LayerNorm, embedding index/token rows.
+// HBM-bound kernels of the ViT path: fp32 -> 16-bit (hi[, lo]) plane packing, LayerNorm, embedding index/token rows.
+// T = bf16 | f16 element type of the planes, NPL = 1 (single plane) | 2 (hi + lo).
 // One wave per row where a row reduction is needed (wave64 shuffles, no LDS); 16-byte vector accesses everywhere.
 #include "dev_common.h"
 #include "kernels.h"
@@ -6,37 +7,38 @@
 namespace vtq {
 namespace {
 
-template <int NSPLIT>
-__device__ __forceinline__ void store4(bf16* dst, int64_t plane, float a, float b, float c, float d) {
-    if constexpr (NSPLIT == 1) {
-        bf16x4 h = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
-        *(bf16x4*)dst = h;
+template <typename T, int NPL>
+__device__ __forceinline__ void store4(T* dst, int64_t plane, float a, float b, float c, float d) {
+    typedef typename Vec<T>::x4 tx4;
+    if constexpr (NPL == 1) {
+        tx4 h = {(T)a, (T)b, (T)c, (T)d};
+        *(tx4*)dst = h;
     } else {
-        bf16x4 h, l;
-        bf16 x, y;
-        split2(a, x, y); h[0] = x; l[0] = y;
-        split2(b, x, y); h[1] = x; l[1] = y;
-        split2(c, x, y); h[2] = x; l[2] = y;
-        split2(d, x, y); h[3] = x; l[3] = y;
-        *(bf16x4*)dst = h;
-        *(bf16x4*)(dst + plane) = l;
+        tx4 h, l;
+        T x, y;
+        split2<T>(a, x, y); h[0] = x; l[0] = y;
+        split2<T>(b, x, y); h[1] = x; l[1] = y;
+        split2<T>(c, x, y); h[2] = x; l[2] = y;
+        split2<T>(d, x, y); h[3] = x; l[3] = y;
+        *(tx4*)dst = h;
+        *(tx4*)(dst + plane) = l;
     }
 }
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t plane,
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t plane,
                                                     int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = ((const float4*)src)[i];
-        store4<NSPLIT>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
     }
 }
 
 // rows [k*BN, (k+1)*BN) from image k (k < nimg: ref, dist[, dist2]); rows >= nimg*BN zero.  K = 768 floats per row.
 struct ImgPtrs { const float* p[3]; };
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, bf16* __restrict__ dst, int64_t plane, int BN, int K4,
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, T* __restrict__ dst, int64_t plane, int BN, int K4,
                                                            int64_t total4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / K4;
@@ -47,14 +49,18 @@ __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg
             const float* sp = img == 0 ? src.p[0] : (img == 1 ? src.p[1] : src.p[2]);
             v = ((const float4*)sp)[(row - (int64_t)img * BN) * K4 + c4];
         }
-        store4<NSPLIT>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
     }
 }
 
 // UvPosEmbedding.forward index (transformer.py:417-421): floor(pos*G) -> i0*G + i1 + 1, evaluated in fp32 like torch;
 // ScaleEmbedding.forward index (transformer.py:396-398): clamp(scale, 0, num_scales-1) + 1.
+// The reference indexes its table with whatever comes out (transformer.py:417-421) and raises IndexError / a device assert for
+// pos outside [0, 1); here an out-of-range index (pos < 0, pos >= 1, NaN) is clamped into the table and reported through
+// *err (bit 0), which vtq_input_errors() reads back: never an out-of-bounds gather.
 __global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __restrict__ pidx, int* __restrict__ sidx,
-                                   int* __restrict__ row_map, int B, int N, int rows_pad, SeqMap sm, int T, int grid, int num_scales) {
+                                   int* __restrict__ row_map, int B, int N, int rows_pad, SeqMap sm, int T, int grid, int num_scales,
+                                   int* __restrict__ err) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows_pad) return;
     const int BN = B * N;
@@ -65,7 +71,10 @@ __global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __res
     const float* pp = pb + (int64_t)rr * 2;
     const float g = (float)grid;
     const float f0 = floorf(pp[0] * g), f1 = floorf(pp[1] * g);
-    pidx[r] = (int)(f0 * g + f1 + 1.0f);
+    const bool ok = f0 >= 0.0f && f0 < g && f1 >= 0.0f && f1 < g;            // false for NaN too
+    if (!ok) atomicOr(err, 1);
+    const float c0 = fminf(fmaxf(f0, 0.0f), g - 1.0f), c1 = fminf(fmaxf(f1, 0.0f), g - 1.0f);   // fmaxf(NaN, 0) = 0
+    pidx[r] = (int)(c0 * g + c1 + 1.0f);
     int si = 0;
     if (sc.p[0]) {
         const float* sb = img == 0 ? sc.p[0] : (img == 1 ? sc.p[1] : sc.p[2]);
@@ -141,9 +150,9 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
     }
 }
 
-template <int V4, int NSPLIT>
+template <int V4, typename T, int NPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, bf16* __restrict__ out, int64_t o_plane,
+                                                        const float* __restrict__ b, T* __restrict__ out, int64_t o_plane,
                                                         int rows) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x & 63;
@@ -151,9 +160,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= rows) return;
     float4 y[V4];
     ln_row<V4>(x + (int64_t)row * H, w, b, lane, y);
-    bf16* o = out + (int64_t)row * H;
+    T* o = out + (int64_t)row * H;
 #pragma unroll
-    for (int i = 0; i < V4; ++i) store4<NSPLIT>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w);
+    for (int i = 0; i < V4; ++i) store4<T, NPL>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w);
 }
 
 // encoder_norm on the two CLS rows of pair b only (transformer.py:376 applies it to all rows; only token 0 is
@@ -186,32 +195,43 @@ inline int grid_for(int64_t work, int block) {
 
 }  // namespace
 
-hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s) {
+// dispatch on (f16, planes) -> K<T, NPL>
+#define VTQ_FMT_DISPATCH(f16_, npl_, CALL)                      \
+    do {                                                        \
+        if (!(f16_) && (npl_) == 1) { CALL(bf16, 1); }          \
+        else if (!(f16_) && (npl_) == 2) { CALL(bf16, 2); }     \
+        else if ((f16_) && (npl_) == 1) { CALL(f16, 1); }       \
+        else if ((f16_) && (npl_) == 2) { CALL(f16, 2); }       \
+        else return hipErrorInvalidValue;                       \
+    } while (0)
+
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s) {
     if (numel % 4) return hipErrorInvalidValue;
     const int64_t n4 = numel / 4;
-    if (nsplit == 1) hipLaunchKernelGGL(split_kernel<1>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, plane, n4);
-    else hipLaunchKernelGGL(split_kernel<3>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, plane, n4);
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((split_kernel<TT, NP>), dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (TT*)dst, plane, n4)
+    VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
+#undef VTQ_CALL
     return hipGetLastError();
 }
 
-hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int nsplit,
-                               hipStream_t s) {
+hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16_,
+                               int planes, hipStream_t s) {
     const int K4 = K / 4;
     const int64_t total4 = (int64_t)rows_pad * K4;
     ImgPtrs ip{{imgs[0], imgs[1], nimg > 2 ? imgs[2] : nullptr}};
-    if (nsplit == 1)
-        hipLaunchKernelGGL(pack_patches_kernel<1>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (bf16*)dst, plane, BN, K4, total4);
-    else
-        hipLaunchKernelGGL(pack_patches_kernel<3>, dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (bf16*)dst, plane, BN, K4, total4);
+#define VTQ_CALL(TT, NP) \
+    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, total4)
+    VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
+#undef VTQ_CALL
     return hipGetLastError();
 }
 
 hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
-                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, hipStream_t s) {
+                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, int* err, hipStream_t s) {
     ImgPtrs pp{{pos[0], pos[1], nimg > 2 ? pos[2] : nullptr}};
     ImgPtrs sp{{sc ? sc[0] : nullptr, sc ? sc[1] : nullptr, (sc && nimg > 2) ? sc[2] : nullptr}};
     hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pp, sp, nimg, pidx, sidx, row_map, B, N, rows_pad,
-                       sm, T, grid, num_scales);
+                       sm, T, grid, num_scales, err);
     return hipGetLastError();
 }
 
@@ -235,15 +255,17 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int nsplit, hipStream_t s) {
+                            int f16_, int planes, hipStream_t s) {
     const dim3 g((rows + 3) / 4), blk(256);
-#define VTQ_LN(V4, NS) hipLaunchKernelGGL((layernorm_kernel<V4, NS>), g, blk, 0, s, x, w, b, (bf16*)out, o_plane, rows)
-    if (H == 768 && nsplit == 1) VTQ_LN(3, 1);
-    else if (H == 768 && nsplit == 3) VTQ_LN(3, 3);
-    else if (H == 1024 && nsplit == 1) VTQ_LN(4, 1);
-    else if (H == 1024 && nsplit == 3) VTQ_LN(4, 3);
-    else return hipErrorInvalidValue;
-#undef VTQ_LN
+    if (H == 768) {
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<3, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows)
+        VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
+#undef VTQ_CALL
+    } else if (H == 1024) {
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<4, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows)
+        VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
+#undef VTQ_CALL
+    } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // libvtamiq_hip.so: C ABI (include/vtamiq_hip.h) around the gfx950 kernels.
 //
-// One engine = one VTAMIQ model instance on one GPU: packed weights (bf16 hi[/lo] planes for the ViT GEMMs, fp32 for
+// One engine = one VTAMIQ model instance on one GPU: packed weights (16-bit hi[/lo] planes for the ViT GEMMs, fp32 for
 // everything else), a workspace sized for the largest (B, N) seen, and the launch sequence of VTAMIQ.forward
 // (modules/vtamiq/vtamiq.py:94-119) with both images of a pair batched as 2B sequences through ONE encoder pass
 // (the reference runs two serial passes with the same weights, vtamiq.py:100-101).
@@ -44,7 +44,7 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 struct Slot {
     void* dst = nullptr;      // destination (fp32 copy) or bf16 hi plane (split)
     int64_t numel = 0;
-    bool split = false;       // true: pack to bf16 planes
+    bool split = false;       // true: pack to 16-bit planes (engine->f16, engine->wpl)
     int64_t plane = 0;        // elements between hi and lo plane
     bool loaded = false;
 };
@@ -61,7 +61,8 @@ struct Rg { std::vector<Rcab> rcabs; float *w, *b; };
 
 struct vtq_engine {
     vtq_config cfg{};
-    int nsplit = 1, npl = 1;
+    Num lin{0, 1}, att{0, 1};          // operand format of the linear layers / of attention (QK^T, PV)
+    int f16 = 0, apl = 1, wpl = 1;     // element type of every plane; planes per activation / per weight tensor
     int H = 0, Mdim = 0, T = 0;
     std::vector<void*> allocs;
     std::unordered_map<std::string, Slot> slots;
@@ -85,9 +86,7 @@ struct vtq_engine {
     float* hhid = nullptr;
     float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr, *h1cls = nullptr;   // CLS-only last layer
     bool cls_prune = true;
-    int nparts = 2;                      // part-batches run on separate streams (VTQ_PARTS; 1 disables)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int* err_flag = nullptr;             // device word: bit 0 = a position outside [0, 1) was clamped (vtq_input_errors)
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
     // profiling
@@ -121,7 +120,7 @@ int add_split(vtq_engine* e, const std::string& name, void* base, int64_t plane,
 
 int alloc_planes(vtq_engine* e, void** p, int64_t* plane, int64_t numel) {
     *plane = numel;
-    return dev_alloc(e, p, (size_t)numel * 2 * e->npl);
+    return dev_alloc(e, p, (size_t)numel * 2 * e->wpl);
 }
 
 int build(vtq_engine* e) {
@@ -196,8 +195,6 @@ int build(vtq_engine* e) {
 
 struct Geometry {
     int S, S_pad, nseq;          // S_pad: row pitch of a sequence (= S: sequences are packed back to back)
-    int nparts, per;             // part-batches (separate streams) and sequences per part
-    int64_t part_rows;           // rows of one part-batch, a multiple of 256 (the GEMM tile height)
     int64_t M_pad, P_pad, rows_alloc;
     SeqMap sm;
 };
@@ -207,25 +204,20 @@ Geometry geometry(const vtq_engine* e, int B, int N, int nimg = 2) {
     Geometry g;
     g.S = N + e->T;
     // No per-sequence padding: attention masks keys >= S (its last 64-key tile and last 128-query block run into the next
-    // sequence's rows, or into the part's tail / the 128 slack rows: finite values, never stored), every other kernel is
-    // row-independent.  Only a part-batch is padded, to the GEMM tile height.
+    // sequence's rows, or into the tail / the 128 slack rows: finite values, never stored), every other kernel is
+    // row-independent.  Only the whole batch is padded, to the GEMM tile height.
     g.S_pad = g.S;
     g.nseq = nimg * B;
-    g.nparts = e->nparts;
-    while (g.nparts > 1 && g.nseq % g.nparts) g.nparts >>= 1;
-    if (e->cfg.num_layers < 2) g.nparts = 1;
-    g.per = g.nseq / g.nparts;
-    g.part_rows = round_up((int64_t)g.per * g.S_pad, 256);
-    g.M_pad = g.nparts * g.part_rows;
+    g.M_pad = round_up((int64_t)g.nseq * g.S_pad, 256);
     g.P_pad = round_up((int64_t)nimg * B * N, 256);
-    g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention over-read slack behind the last part
-    g.sm = SeqMap{g.S_pad, g.per, (int)(g.part_rows - (int64_t)g.per * g.S_pad)};
+    g.rows_alloc = (g.M_pad > g.P_pad ? g.M_pad : g.P_pad) + 128;   // +128: attention over-read slack behind the last sequence
+    g.sm = SeqMap{g.S_pad, g.nseq, (int)(g.M_pad - (int64_t)g.nseq * g.S_pad)};
     return g;
 }
 
-// capacity for up to `B` sequence pairs however a call partitions them (<= 4 parts, each padded to 256 rows)
+// capacity for up to `B` sequence pairs
 int64_t capacity_rows(const vtq_engine* e, int B, int N) {
-    const int64_t seq_rows = round_up((int64_t)2 * B * (N + e->T), 256) + 4 * 256;
+    const int64_t seq_rows = round_up((int64_t)2 * B * (N + e->T), 256);
     const int64_t patch_rows = round_up((int64_t)2 * B * N, 256);
     return (seq_rows > patch_rows ? seq_rows : patch_rows) + 128;
 }
@@ -235,8 +227,8 @@ size_t workspace_bytes(const vtq_engine* e, int B, int N) {
     const int64_t H = e->H, Wmax = (3 * H > e->Mdim ? 3 * H : e->Mdim);
     size_t b = 0;
     b += (size_t)rows * H * 4;                            // residual stream fp32
-    b += (size_t)rows * H * 2 * e->npl;                   // LN / attention output planes
-    b += (size_t)rows * Wmax * 2 * e->npl;                // qkv | mlp hidden | packed patches planes
+    b += (size_t)rows * H * 2 * e->apl;                   // LN / attention output planes
+    b += (size_t)rows * Wmax * 2 * e->apl;                // qkv | mlp hidden | packed patches planes
     b += (size_t)P_pad * 4 * 3;                           // pos/scale indices, row map
     b += (size_t)2 * B * H * 4 * 6;                       // head ping-pong buffers (pairwise: 2 scores per item)
     b += (size_t)2 * B * (4 * H + e->Mdim) * 4;           // CLS-only last-layer rows
@@ -256,8 +248,8 @@ int reserve(vtq_engine* e, int B, int N) {
     e->ln_plane = g.rows_alloc * H;
     e->big_plane = g.rows_alloc * Wmax;
     if (dev_alloc(e, (void**)&e->x, (size_t)g.rows_alloc * H * 4, true) ||
-        dev_alloc(e, &e->lnbuf, (size_t)e->ln_plane * 2 * e->npl, true) ||
-        dev_alloc(e, &e->big, (size_t)e->big_plane * 2 * e->npl, true) ||
+        dev_alloc(e, &e->lnbuf, (size_t)e->ln_plane * 2 * e->apl, true) ||
+        dev_alloc(e, &e->big, (size_t)e->big_plane * 2 * e->apl, true) ||
         dev_alloc(e, (void**)&e->pidx, (size_t)g.P_pad * 4, true) || dev_alloc(e, (void**)&e->sidx, (size_t)g.P_pad * 4, true) ||
         dev_alloc(e, (void**)&e->row_map, (size_t)g.P_pad * 4, true) ||
         dev_alloc(e, (void**)&e->hhid, (size_t)2 * nB * H * 4, true))
@@ -270,8 +262,8 @@ int reserve(vtq_engine* e, int B, int N) {
         return 1;
     // finite contents everywhere: padded rows are computed on (never consumed) and must not breed NaNs
     HIP_TRY(hipMemset(e->x, 0, (size_t)g.rows_alloc * H * 4));
-    HIP_TRY(hipMemset(e->lnbuf, 0, (size_t)e->ln_plane * 2 * e->npl));
-    HIP_TRY(hipMemset(e->big, 0, (size_t)e->big_plane * 2 * e->npl));
+    HIP_TRY(hipMemset(e->lnbuf, 0, (size_t)e->ln_plane * 2 * e->apl));
+    HIP_TRY(hipMemset(e->big, 0, (size_t)e->big_plane * 2 * e->apl));
     HIP_TRY(hipDeviceSynchronize());
     e->capB = nB;
     e->capN = nN;
@@ -294,28 +286,23 @@ struct Prof {
 };
 
 
-struct Part { int seq0, nseq; int64_t rows; hipStream_t s; };
-
-// All encoder layers for the sequences [seq0, seq0 + nseq) of one part-batch, enqueued on pt.s.
-int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune) {
+// All encoder layers for the g.nseq sequences, enqueued on s.
+int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     const vtq_config& c = e->cfg;
-    const int H = e->H, Md = e->Mdim, T = e->T, ns = e->nsplit, L = c.num_layers;
-    hipStream_t s = pt.s;
-    const int M = (int)pt.rows;
-    const int64_t row0 = (int64_t)(pt.seq0 / g.per) * g.part_rows;     // parts start at multiples of part_rows
-    const int64_t Wmax = (3 * H > Md ? 3 * H : Md);
-    float* x = e->x + row0 * H;
-    char* lnb = (char*)e->lnbuf + row0 * H * 2;
-    char* big = (char*)e->big + row0 * Wmax * 2;             // each part owns a contiguous chunk: QKV (ld 3H) and MLP hidden (ld M) alias inside it only
-    float *xcls = e->xcls + (int64_t)pt.seq0 * H, *lncls = e->lncls + (int64_t)pt.seq0 * H, *qcls = e->qcls + (int64_t)pt.seq0 * H,
-          *acls = e->acls + (int64_t)pt.seq0 * H, *h1cls = e->h1cls + (int64_t)pt.seq0 * Md;
+    const int H = e->H, Md = e->Mdim, T = e->T, L = c.num_layers, f16 = e->f16, apl = e->apl, wpl = e->wpl;
+    const Num lin = e->lin;
+    const int M = (int)g.M_pad;
+    float* x = e->x;
+    char* lnb = (char*)e->lnbuf;
+    char* big = (char*)e->big;                               // QKV (ld 3H) and the MLP hidden (ld M) alias: never live together
+    float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls, *acls = e->acls, *h1cls = e->h1cls;
     const int64_t trace_stride = (int64_t)g.nseq * T * H;
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
         if (prune && i == L - 1) {
             // ---- last layer: K/V for every row, everything else for the 2B CLS rows only (cls_tail.hip) ------------
-            const int R = pt.nseq;
-            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, ns, s)); }
+            const int R = g.nseq;
+            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
             {
                 Prof p(e, s, VTQ_K_QKV);
                 GemmArgs a{};
@@ -323,55 +310,55 @@ int run_encoder(vtq_engine* e, const Geometry& g, const Part& pt, bool prune) {
                 a.W = (const char*)Ly.wqkv + (size_t)H * H * 2; a.w_plane = Ly.pqkv;
                 a.M = M; a.N = 2 * H; a.K = H; a.bias = Ly.bqkv + H;
                 a.out = big + (size_t)H * 2; a.o_plane = e->big_plane; a.ldo = 3 * H;
-                HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+                HIP_TRY(launch_gemm(a, lin, EPI_BIAS, s));
             }
             {
                 Prof p(e, s, VTQ_K_HEAD);
                 HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, s));
-                HIP_TRY(launch_rows_linear(lncls, Ly.wqkv, Ly.pqkv, ns, Ly.bqkv, nullptr, nullptr, qcls, R, H, H, 0, s));
-                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, ns, s));
+                HIP_TRY(launch_rows_linear(lncls, Ly.wqkv, Ly.pqkv, f16, wpl, Ly.bqkv, nullptr, nullptr, qcls, R, H, H, 0, s));
+                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, f16, apl, s));
             }
             {
                 Prof p(e, s, VTQ_K_HEAD);
-                HIP_TRY(launch_rows_linear(acls, Ly.wo, Ly.po, ns, Ly.bo, Ly.g1, xcls, xcls, R, H, H, 2, s));
+                HIP_TRY(launch_rows_linear(acls, Ly.wo, Ly.po, f16, wpl, Ly.bo, Ly.g1, xcls, xcls, R, H, H, 2, s));
             }
             { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s)); }
-            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, ns, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
-            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, ns, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
+            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, f16, wpl, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
+            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, f16, wpl, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
             break;
         }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, ns, s)); }
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
         {
             Prof p(e, s, VTQ_K_QKV);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
             a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = big; a.o_plane = e->big_plane; a.ldo = 3 * H;
-            HIP_TRY(launch_gemm(a, ns, EPI_BIAS, s));
+            HIP_TRY(launch_gemm(a, lin, EPI_BIAS, s));
         }
-        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, pt.nseq, g.S, g.S_pad, H, ns, s)); }
+        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s)); }
         {
             Prof p(e, s, VTQ_K_OUTPROJ);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
             a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = x;
-            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+            HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
         }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, ns, s)); }
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, f16, apl, s)); }
         {
             Prof p(e, s, VTQ_K_FC1);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
             a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = big; a.o_plane = e->big_plane; a.ldo = Md;
-            HIP_TRY(launch_gemm(a, ns, EPI_BIAS_GELU, s));
+            HIP_TRY(launch_gemm(a, lin, EPI_BIAS_GELU, s));
         }
         {
             Prof p(e, s, VTQ_K_FC2);
             GemmArgs a{};
             a.A = big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
             a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = x;
-            HIP_TRY(launch_gemm(a, ns, EPI_RESID, s));
+            HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
         }
-        if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride + (int64_t)pt.seq0 * T * H, pt.nseq, SeqMap{g.S_pad, pt.nseq, 0}, T, H, s));
+        if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride, g.nseq, g.sm, T, H, s));
     }
     return 0;
 }
@@ -394,23 +381,28 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     if (c.num_layers < 1 || c.pos_grid < 1 || c.num_extra_tokens < 0) return fail("bad topology");
     if (c.calibrate && (c.num_rgs < 1 || c.num_rcabs < 1 || c.ca_hidden < 4 || c.ca_hidden % 4 || c.ca_hidden > 256))
         return fail("bad DiffNet topology (rgs %d, rcabs %d, ca_hidden %d)", c.num_rgs, c.num_rcabs, c.ca_hidden);
-    if (c.precision != VTQ_PREC_BF16 && c.precision != VTQ_PREC_BF16X3) return fail("unknown precision %d", c.precision);
     vtq_engine* e = new vtq_engine();
     e->cfg = c;
-    e->nsplit = c.precision == VTQ_PREC_BF16 ? 1 : 3;
-    e->npl = c.precision == VTQ_PREC_BF16 ? 1 : 2;
+    switch (c.precision) {
+        case VTQ_PREC_BF16:   e->lin = Num{0, 1}; e->att = Num{0, 1}; break;
+        case VTQ_PREC_BF16X3: e->lin = Num{0, 3}; e->att = Num{0, 3}; break;
+        case VTQ_PREC_FP16:   e->lin = Num{1, 1}; e->att = Num{1, 1}; break;
+        case VTQ_PREC_FP16X3: e->lin = Num{1, 3}; e->att = Num{1, 3}; break;
+        case VTQ_PREC_FP16X2: e->lin = Num{1, 2}; e->att = Num{1, 3}; break;     // attention keeps the 3-term form
+        default: delete e; return fail("unknown precision %d", c.precision);
+    }
+    e->f16 = e->lin.f16;
+    e->apl = e->lin.apl();
+    e->wpl = e->lin.wpl();
     e->H = c.hidden_size;
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
     { const char* np = getenv("VTQ_NO_CLS_PRUNE"); e->cls_prune = !(np && np[0] == '1'); }
-    { const char* ps = getenv("VTQ_PARTS"); if (ps) e->nparts = atoi(ps); if (e->nparts != 1 && e->nparts != 2 && e->nparts != 4) e->nparts = 2; }
-    if (e->nparts > 1) {
-        bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < e->nparts - 1; ++i)
-            ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { vtq_destroy(e); return fail("vtq_create: stream/event creation failed"); }
+    if (hipMalloc((void**)&e->err_flag, 16) != hipSuccess || hipMemset(e->err_flag, 0, 16) != hipSuccess) {
+        vtq_destroy(e);
+        return fail("vtq_create: device allocation failed");
     }
+    e->allocs.push_back(e->err_flag);
     if (build(e)) { vtq_destroy(e); return 1; }
     *out = e;
     return 0;
@@ -423,11 +415,6 @@ void vtq_destroy(vtq_handle e) {
     for (void* p : e->ws_allocs) (void)hipFree(p);
     for (auto& ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    for (int i = 0; i < 3; ++i) {
-        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-        if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-    }
     delete e;
 }
 
@@ -441,7 +428,7 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         if (it == e->slots.end()) return fail("vtq_load_weights: unexpected tensor '%s'", d.name);
         Slot& sl = it->second;
         if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
-        if (sl.split) HIP_TRY(launch_split_bf16(d.data, sl.dst, sl.plane, sl.numel, e->nsplit, s));
+        if (sl.split) HIP_TRY(launch_split(d.data, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
         else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
     }
@@ -505,14 +492,14 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     const int ndist = nimg - 1, HB = ndist * B;            // head batch
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(e, B, N, nimg);
-    const int H = e->H, T = e->T, ns = e->nsplit;
+    const int H = e->H, T = e->T;
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
-        HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, ns, s));
+        HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s));
         HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
-                                   c.pos_grid, c.num_scales, s));
+                                   c.pos_grid, c.num_scales, e->err_flag, s));
         HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
         HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.sm, T, H, s));
     }
@@ -525,31 +512,15 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         a.bias = e->bpatch; a.x = e->x;
         a.row_map = e->row_map; a.idx1 = e->pidx; a.table1 = e->pos_table;
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
-        HIP_TRY(launch_gemm(a, ns, EPI_EMBED, s));
+        HIP_TRY(launch_gemm(a, e->lin, EPI_EMBED, s));
     }
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
 
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
-    const bool prune = e->cls_prune && !e->trace;      // the trace tap needs every token row of the last layer
-    // Part-batches on separate streams: the dispatcher then always has ready workgroups of a DIFFERENT kernel to fill
-    // partially occupied rounds (N = 768 GEMMs are 1.5 rounds at B = 32), and one part's store bursts / LayerNorm overlap
-    // another part's MFMA loops.  Parts are contiguous sequence ranges (ref images first), all kernels are row-independent.
-    if (g.nparts > 1) {
-        HIP_TRY(hipEventRecord(e->ev_fork, s));
-        for (int pi = 0; pi < g.nparts; ++pi) {
-            hipStream_t ps = pi == 0 ? s : e->side[pi - 1];
-            if (pi) HIP_TRY(hipStreamWaitEvent(ps, e->ev_fork, 0));
-            Part pt{pi * g.per, g.per, g.part_rows, ps};
-            if (run_encoder(e, g, pt, prune)) return 1;
-            if (pi) {
-                HIP_TRY(hipEventRecord(e->ev_join[pi - 1], ps));
-                HIP_TRY(hipStreamWaitEvent(s, e->ev_join[pi - 1], 0));
-            }
-        }
-    } else {
-        Part pa{0, g.nseq, g.M_pad, s};
-        if (run_encoder(e, g, pa, prune)) return 1;
-    }
+    // the trace tap needs every token row of the last layer; sequences longer than the CLS kernel's LDS score buffer run the
+    // full last layer instead (same result)
+    const bool prune = e->cls_prune && !e->trace && g.S <= cls_attention_max_seq();
+    if (run_encoder(e, g, s, prune)) return 1;
 
     // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------
     {
@@ -596,40 +567,55 @@ int vtq_forward_pairwise(vtq_handle e, const float* const* patches, const float*
     return forward_impl(e, 3, patches, pos, sc, B, N, q_out, stream);
 }
 
-// ---- per-kernel entry points -------------------------------------------------------------------------------------
-int vtq_k_split_bf16(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t nsplit, void* stream) {
-    HIP_TRY(launch_split_bf16(src, dst, plane_stride, numel, nsplit, (hipStream_t)stream));
+int vtq_input_errors(vtq_handle e, int32_t* flags, void* stream) {
+    if (!e || !flags) return fail("vtq_input_errors: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, e->err_flag, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(e->err_flag, 0, 4, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *flags = h;
     return 0;
 }
 
-int vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t* out, int32_t cap) {
-    if (M < 256 || N < 256 || M % 256 || N % 256) return -1;
-    const std::vector<int> v = gemm_tile_schedule(M / 256, N / 256);
+// ---- per-kernel entry points -------------------------------------------------------------------------------------
+int vtq_k_split(const float* src, void* dst, int64_t plane_stride, int64_t numel, int32_t f16, int32_t planes, void* stream) {
+    HIP_TRY(launch_split(src, dst, plane_stride, numel, f16, planes, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_gemm_schedule(int32_t M, int32_t N, int32_t K, int32_t wplanes, int32_t* out, int32_t cap) {
+    if (M < 256 || N < 256 || M % 256 || N % 256 || K < 1 || wplanes < 1 || wplanes > 2) return -1;
+    const std::vector<int> v = gemm_tile_schedule(M / 256, N / 256, K, wplanes);
     if (out)
         for (size_t i = 0; i < v.size() && (int32_t)i < cap; ++i) out[i] = v[i];
     return (int)v.size();
 }
 
 int vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t N, int32_t K,
-               int32_t nsplit, int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out_bf16,
+               int32_t num, int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out16,
                int64_t o_plane, int32_t ldo, void* stream) {
     if (epilogue < 0 || epilogue > 2) return fail("vtq_k_gemm: epilogue %d", epilogue);
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm)) return fail("vtq_k_gemm: operand format code %d", num);
     GemmArgs a{};
     a.A = A; a.a_plane = a_plane; a.lda = lda; a.W = W; a.w_plane = w_plane; a.M = M; a.N = N; a.K = K;
-    a.bias = bias; a.gamma = gamma; a.x = x_f32; a.out = out_bf16; a.o_plane = o_plane; a.ldo = ldo;
-    HIP_TRY(launch_gemm(a, nsplit, epilogue, (hipStream_t)stream));
+    a.bias = bias; a.gamma = gamma; a.x = x_f32; a.out = out16; a.o_plane = o_plane; a.ldo = ldo;
+    HIP_TRY(launch_gemm(a, nm, epilogue, (hipStream_t)stream));
     return 0;
 }
 
 int vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int32_t rows, int32_t H,
-                    int32_t nsplit, void* stream) {
-    HIP_TRY(launch_layernorm(x, w, b, out, o_plane, rows, H, nsplit, (hipStream_t)stream));
+                    int32_t f16, int32_t planes, void* stream) {
+    HIP_TRY(launch_layernorm(x, w, b, out, o_plane, rows, H, f16, planes, (hipStream_t)stream));
     return 0;
 }
 
 int vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int32_t nseq, int32_t S, int32_t S_pad,
-                    int32_t H, int32_t nsplit, void* stream) {
-    HIP_TRY(launch_attention(qkv, plane, out, o_plane, nseq, S, S_pad, H, nsplit, (hipStream_t)stream));
+                    int32_t H, int32_t num, void* stream) {
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm) || nm.terms == 2) return fail("vtq_k_attention: operand format code %d", num);
+    HIP_TRY(launch_attention(qkv, plane, out, o_plane, nseq, S, S_pad, H, nm, (hipStream_t)stream));
     return 0;
 }
 

@@ -1,11 +1,11 @@
-// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues.
+// 16-bit MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues, persistent over a tile schedule.
 //
 // Replaces every torch.nn.Linear / patch Conv2d on the ViT path of the reference
 // (modules/VisionTransformer/transformer.py:138-140,154-156,169 [QKV/out], :205-206,212-215 [MLP],
 //  :475-480,531-532 [patch embedding as GEMM]).
 //
 // Design (cdna_hip_programming.md section 5, "256^2 8-phase template", re-derived for this shape family):
-//   * 256x256 output tile per 512-thread workgroup, 8 waves, mfma_f32_16x16x32_bf16, 128 fp32 accumulators per lane.
+//   * 256x256 output tile per 512-thread workgroup, 8 waves, mfma_f32_16x16x32_{bf16,f16}, 128 fp32 accumulators per lane.
 //   * Both operands are K-contiguous (torch Linear layout) and go global -> LDS by 16-byte LDS-DMA
 //     (global_load_lds_dwordx4).  The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128
 //     fragment reads are removed by XOR-swizzling the 16-byte chunk index on the SOURCE address and on the read
@@ -16,20 +16,29 @@
 //     4 half-tiles ahead under a COUNTED vmcnt (never 0 in the steady state) and raw s_barrier.
 //   * Ping-pong: waves 0-3 and 4-7 (the two waves of each SIMD) run one barrier apart, so while one wave of a SIMD
 //     issues its MFMA cluster the other issues LDS reads + DMA and waits for them.
-//       2-phase schedule (default): per K tile   A: read A0,B0,B1 | 32 (x3: 48) MFMAs on quadrants (0,0),(0,1)
-//                                                 B: read A1       | 32 (x3: 48) MFMAs on quadrants (1,1),(1,0)
+//       2-phase schedule: per K tile   A: read A0,W0,W1 | MFMAs on quadrants (0,0),(0,1)
+//                                      B: read A1       | MFMAs on quadrants (1,1),(1,0)
 //       LDS reads are retired (lgkmcnt(0)) BEFORE the phase barrier: the MFMA cluster starts right after the barrier and a
-//       region may be re-staged one phase after its last read.  Measured fixed cost per barrier interval ~250 cycles, so
-//       the longer clusters lift MFMA utilisation over a 4-phase form (16 MFMAs per interval; measured, removed).
+//       region may be re-staged one phase after its last read.
 //   * Operands are swapped in the MFMA (W fragment as A-operand): a lane holds 4 consecutive output columns of one row.
 //   * Epilogues stage through LDS so every global access is a full row segment, 16 bytes per lane.
-//   * NSPLIT == 3 ("bf16x3"): A and W arrive as hi/lo bf16 planes; each product is hi*hi + hi*lo + lo*hi into the same fp32
-//     accumulator (3 MFMAs per 4 fragment reads); BK is 32 instead of 64 so regions keep their 16 KiB.
-//   * Workgroups follow a host-built tile schedule (build_schedule): XCD-contiguous tile runs whose last round is filled
-//     with 128-row half tiles.
+//   * TERMS = MFMAs per product (operand format):
+//       1: a*w                                   one 16-bit plane each, BK = 64
+//       2: (a_hi + a_lo)*w                       activation hi/lo planes, weight single plane, BK = 32
+//       3: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo     hi/lo planes for both, BK = 32
+//     into the same fp32 accumulator.
+//   * PERSISTENT: at most one workgroup per CU walks its own list of tiles (host-built schedule).  The DMA ring runs
+//     straight through a tile boundary: the next tile's first K tile is staged during the current tile's last K tile, so
+//     it lands under the epilogue; only the K tile that would overwrite the epilogue's LDS staging area is deferred to
+//     the end of the epilogue.  Epilogue stores are never drained (counted vmcnt steps over them).
+//   * Schedule: each XCD (workgroups b, b+8, ...) owns a contiguous run of tiles, ordered column-group-major so that the
+//     32 tiles it works on at a time are (32/cg row panels) x (cg column tiles) with the cg W tiles L2-resident; the run
+//     ends with 128-row half tiles so the last round is filled in half-tile granules.
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -47,29 +56,26 @@ template <int BK> __device__ __forceinline__ int swz(int row) {
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-// allow `n` LDS-DMA instructions (2 per half-tile) to stay in flight; n is wave-uniform
-__device__ __forceinline__ void wait_dma(int n) {
-    if (n >= 8) wait_vm<8>();
-    else if (n >= 6) wait_vm<6>();
-    else if (n >= 4) wait_vm<4>();
-    else if (n >= 2) wait_vm<2>();
-    else wait_vm<0>();
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+constexpr int kHalfRows = 128;
+
 // ---- shared epilogue of the ping-pong kernels -------------------------------------------------------------------------
-template <int NSPLIT, int EPI, int MH>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
+// VMEM instructions one wave issues in the epilogue after its bias / gamma loads (all unconditional in the staged forms):
+// stores, and for the residual form the interleaved loads of x.  The counted wait of a following tile steps over them.
+template <int OPL, int EPI, int MH> constexpr int epilogue_vmem_ops() {
+    return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? MH * 2 * OPL * 4 : MH * 4 * 8;
+}
+
+template <typename T, int OPL, int EPI, int MH>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
                                             int fr, int fq, int64_t m0, int n0) {
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    typedef typename Vec<T>::x4 tx4;
     // acc[mh][nh][mi][ni][reg]: m = m0 + mh*128 + wr*64 + mi*16 + fr ; n = n0 + nh*128 + wc*32 + ni*16 + fq*4 + reg
-    // bf16 outputs and the fp32 residual update go through LDS (free after the main loop) so that every global access is a
-    // full row segment: one wave instruction = 2 rows x 512 B (bf16) or 1 row x 1 KiB (fp32), 16 bytes per lane.
+    // 16-bit outputs and the fp32 residual update go through LDS (free after the main loop) so that every global access is a
+    // full row segment: one wave instruction = 2 rows x 512 B (16-bit) or 1 row x 1 KiB (fp32), 16 bytes per lane.
     float4 b4[2][2], g4[2][2];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
@@ -80,21 +86,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             if constexpr (EPI == EPI_RESID) g4[nh][ni] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
         }
 
-    // The staged forms work in CHUNKS through two LDS images (above the first K-tile buffer, see STG below): in every barrier
-    // interval the workgroup copies chunk k-1 out to global memory (ds_read_b128 -> 16-byte row-segment stores) and converts
-    // chunk k into the other image, so the stores' address-path time hides behind the next chunk's VALU / LDS writes.
-    constexpr int STG = 65536;                          // staging base: the ring's second K-tile buffer and the slack above it
+    // The staged forms work in CHUNKS through two LDS images (in the ring's second K-tile buffer and the slack above it; the
+    // first buffer may already be receiving the next tile): in every barrier interval the workgroup copies chunk k-1 out to
+    // global memory (ds_read_b128 -> 16-byte row-segment stores) and converts chunk k into the other image.
+    constexpr int STG = 65536;
     auto interval_end = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // chunk (mh, q): the 64 rows {mh*128 + wr*64 + (2q + e)*16 + fr}, image row = wr*32 + e*16 + fr; one pass per plane
-        constexpr int RS = 528;                         // 256 bf16 + 16 B pad: rows stay 16-B aligned for ds_read_b128
+        constexpr int RS = 528;                         // 256 x 16 bit + 16 B pad: rows stay 16-B aligned for ds_read_b128
         constexpr int IMG = 64 * RS;
-        constexpr int NP = (NSPLIT == 1) ? 1 : 2;
+        constexpr int NP = OPL;
         constexpr int NPASS = MH * 2 * NP;
-        bf16x4 lo[(NSPLIT == 1) ? 1 : 8];               // lo plane of the chunk in flight (written by the next pass)
+        tx4 lo[(NP == 1) ? 1 : 8];                      // lo plane of the chunk in flight (written by the next pass)
         auto convert = [&](int pass) {                  // pass = (mh*2 + q)*NP + pl; all indices fold after unrolling
             const int pl = pass % NP, cq = pass / NP, mh = cq >> 1, q = cq & 1;
             char* img = smem + STG + (pass & 1) * IMG;
@@ -107,7 +113,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                         const int lrow = wr * 32 + e * 16 + fr;
                         const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
                         const int li = (e * 2 + nh) * 2 + ni;
-                        bf16x4 h;
+                        tx4 h;
                         if (pl == 0) {
                             const f32x4 a = acc[mh][nh][2 * q + e][ni];
                             const float4 bb = b4[nh][ni];
@@ -116,25 +122,25 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
                             }
-                            if constexpr (NSPLIT == 1) {
-                                h = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            if constexpr (NP == 1) {
+                                h = tx4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                             } else {
-                                bf16x4 l;
+                                tx4 l;
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) { bf16 x, y; split2(v[k], x, y); h[k] = x; l[k] = y; }
+                                for (int k = 0; k < 4; ++k) { T x, y; split2<T>(v[k], x, y); h[k] = x; l[k] = y; }
                                 lo[li] = l;
                             }
                         } else {
-                            h = lo[(NSPLIT == 1) ? 0 : li];
+                            h = lo[(NP == 1) ? 0 : li];
                         }
-                        *(bf16x4*)(img + lrow * RS + col * 2) = h;
+                        *(tx4*)(img + lrow * RS + col * 2) = h;
                     }
         };
         auto copy_out = [&](int pass) {
             const int pl = pass % NP, cq = pass / NP, mh = cq >> 1, q = cq & 1;
             const char* img = smem + STG + (pass & 1) * IMG;
             const int c16 = tid & 31, r0 = tid >> 5;
-            bf16* og = (bf16*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
+            T* og = (T*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {            // image row ps*16 + r0 = (wr = ps>>1, e = ps&1, fr = r0)
                 const int grow = mh * 128 + (ps >> 1) * 64 + (2 * q + (ps & 1)) * 16 + r0;
@@ -142,12 +148,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                 store_nt16(og + (int64_t)grow * p.ldo, v);
             }
         };
+        // Within an interval the two wave groups (the two waves of every SIMD) run the two steps in OPPOSITE order -- they touch
+        // different images, so either order is valid -- so that one wave's VALU conversion runs while its SIMD partner sits in
+        // the store-issue queue, instead of both queueing and then both converting.
         convert(0);
         interval_end();
 #pragma unroll
         for (int pass = 1; pass < NPASS; ++pass) {
-            copy_out(pass - 1);
-            convert(pass);
+            if (wr == 0) { copy_out(pass - 1); convert(pass); }
+            else { convert(pass); copy_out(pass - 1); }
             interval_end();
         }
         copy_out(NPASS - 1);
@@ -235,127 +244,143 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
     }
 }
 
-// ---- common prologue of both schedules ----------------------------------------------------------------------------------
-// Tile descriptor of a workgroup.  With a schedule (GemmArgs::sched, built on the host by build_schedule below) block b runs
-// sched[b] = (tile << 2) | kind, kind 0 = full 256x256 tile, 1 / 2 = top / bottom 128-row half of it; without one the blocks
-// are remapped so that consecutive tiles (sharing an A row panel) land on one XCD's L2.
-struct Tile { int64_t m0; int n0; int half; };
-__device__ __forceinline__ Tile tile_of_block(const GemmArgs& p) {
-    const int ntn = p.N / 256, ntm = p.M / 256;
-    int bid = blockIdx.x, kind = 0;
-    if (p.sched) {
-        const int d = p.sched[bid];
-        bid = d >> 2;
-        kind = d & 3;
-    } else {
-        const int nwg = ntn * ntm;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective XCD-contiguous remap
-    }
-    const int tm = bid / ntn, tn = bid - tm * ntn;
-    return Tile{(int64_t)tm * 256 + (kind == 2 ? 128 : 0), tn * 256, kind != 0};
-}
-
-#define VTQ_PP_COMMON()                                                                                                  \
-    constexpr int BK = (NSPLIT == 1) ? 64 : 32;                                                                          \
-    constexpr int ROWB = BK * 2;                                                                                          \
-    constexpr int REG_B = 16384; /* one half-tile region (all planes) */                                                  \
-    constexpr int BUF_B = 4 * REG_B; /* one K tile: regions 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1 */     \
-    constexpr int NFA = 8, NFB = 4;                                                                                       \
-    extern __shared__ __attribute__((aligned(16))) char smem[];                                                           \
-    const int tid = threadIdx.x;                                                                                          \
-    const int lane = tid & 63;                                                                                            \
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                            \
-    const int wr = wave >> 2, wc = wave & 3;                                                                              \
-    const int fr = lane & 15, fq = lane >> 4;                                                                             \
-    const Tile tl = tile_of_block(p);                                                                              \
-    const int64_t m0 = tl.m0;                                                                                             \
-    const int n0 = tl.n0;                                                                                                 \
-    const bf16* __restrict__ Ag = (const bf16*)p.A + m0 * p.lda;                                                          \
-    const bf16* __restrict__ Wg = (const bf16*)p.W + (int64_t)n0 * p.K;                                                   \
-    const int nkt = p.K / BK;                                                                                             \
-    /* DMA source offsets of this thread inside a half-tile (two rounds of 512 x 16 B; NSPLIT 3: round == plane) */       \
-    int64_t a_off[2], w_off[2];                                                                                           \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                       \
-        if constexpr (NSPLIT == 1) {                                                                                      \
-            const int slot = r * 512 + tid;                                                                               \
-            const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);                                                     \
-            a_off[r] = (int64_t)row * p.lda + c * 8;                                                                      \
-            w_off[r] = (int64_t)row * p.K + c * 8;                                                                        \
-        } else {                                                                                                          \
-            const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);                                                       \
-            a_off[r] = r * p.a_plane + (int64_t)row * p.lda + c * 8;                                                      \
-            w_off[r] = r * p.w_plane + (int64_t)row * p.K + c * 8;                                                        \
-        }                                                                                                                 \
-    }                                                                                                                     \
-    /* stage half-tile region r of K tile kt (caller guarantees kt < nkt) */                                              \
-    auto stage = [&](int kt, int r) {                                                                                     \
-        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;                                                    \
-        const bool isA = (r == 0 || r == 3);                                                                              \
-        const int half = (r >= 2) ? 1 : 0;                                                                                \
-        const bf16* base = isA ? Ag + (int64_t)half * 128 * p.lda + kt * BK : Wg + (int64_t)half * 128 * p.K + kt * BK;   \
-        glds16(base + (isA ? a_off[0] : w_off[0]), dst);                                                                  \
-        glds16(base + (isA ? a_off[1] : w_off[1]), dst + 8192);                                                           \
-    };                                                                                                                    \
-    /* fragment read offsets inside a region: x = k-step (NSPLIT 1) or plane (NSPLIT 3) */                                \
-    int a_rd[2], b_rd[2];                                                                                                 \
-    _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                                       \
-        if constexpr (NSPLIT == 1) {                                                                                      \
-            const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;                                                             \
-            a_rd[x] = (wr * 64 + fr) * ROWB + ch;                                                                         \
-            b_rd[x] = (wc * 32 + fr) * ROWB + ch;                                                                         \
-        } else {                                                                                                          \
-            const int ch = (fq ^ swz<32>(fr)) << 4;                                                                       \
-            a_rd[x] = x * 8192 + (wr * 64 + fr) * ROWB + ch;                                                              \
-            b_rd[x] = x * 8192 + (wc * 32 + fr) * ROWB + ch;                                                              \
-        }                                                                                                                 \
-    }                                                                                                                     \
-    f32x4 acc[2][2][4][2];                                                                                                \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                         \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                     \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};                \
-    bf16x8 fa[NFA], fb0[NFB], fb1[NFB];                                                                                   \
-    auto read_a = [&](const char* reg) {                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const bf16x8*)(reg + a_rd[x] + i * 16 * ROWB); \
-    };                                                                                                                    \
-    auto read_b = [&](const char* reg, bf16x8(&fb)[NFB]) {                                                                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const bf16x8*)(reg + b_rd[x] + j * 16 * ROWB); \
-    };                                                                                                                    \
-    auto mma = [&](f32x4(&c)[4][2], const bf16x8(&fb)[NFB]) {                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
-                if constexpr (NSPLIT == 1) {                                                                              \
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j], 0, 0, 0);    \
-                } else {                                                                                                  \
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 0], fa[i * 2 + 1], c[i][j], 0, 0, 0);    \
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 0], c[i][j], 0, 0, 0);    \
-                }                                                                                                         \
-            }                                                                                                             \
-    };
-
 // =====================================================================================================================
-// 2-phase ping-pong schedule.
-//   DMA groups in issue order: g = 2k: {A0, W0, W1} of K tile k (6 DMA instructions); g = 2k+1: {A1} of tile k (2).
-//   prologue issues groups 0,1,2; phase A(kt) issues group 2kt+3, phase B(kt) issues group 2kt+4.
-//   phase A(kt) reads A0,W0,W1 (waited for in B(kt-1) / prologue) and waits for group 2kt+1 (read in B(kt));
-//   phase B(kt) reads A1 and waits for group 2kt+2 (read in A(kt+1)).
+// Persistent 2-phase ping-pong kernel.
+//
+// DMA groups of a FULL tile, in issue order: g(2k) = {A0, W0, W1} of K tile k (GE instructions per wave), g(2k+1) = {A1} of K
+// tile k (GO).  Phase A(kt) issues g(2kt+3), phase B(kt) issues g(2kt+4); the K-tile index runs on INTO THE NEXT TILE of this
+// workgroup's list (K tile nkt + j of the current tile = K tile j of the next), except g(2 nkt + 2) = {A0, W0, W1} of the next
+// tile's K tile 1: its buffer is the epilogue's staging area, so it is issued after the epilogue.
+//   phase A(kt) reads A0,W0,W1 (waited for in B(kt-1) / before the loop) and waits for g(2kt+1) (read in B(kt));
+//   phase B(kt) reads A1 and waits for g(2kt+2) (read in A(kt+1)); the last B of a tile waits for nothing.
 //   WAR: a region is read (and the read retired by lgkmcnt(0)) before its reader passes the phase barrier; the other wave
 //        group re-stages it in the NEXT phase, i.e. after that barrier.  RAW: a group is waited for by every wave one phase
 //        before the first read, and both wave groups' waits precede the barrier that opens the reading phase.
+//   vmcnt counts loads, LDS-DMA and stores together in issue order, so the wait that opens a chained tile allows for the
+//   epilogue's VMEM operations (EOPS, all unconditional) behind the groups it needs: stores are never drained for their own
+//   sake; the first group issued AFTER the stores (g2) is waited for one K tile later.
 //
 // Half tiles (128 x 256, rows of A half 0 only) are phase A alone: one group {A0, W0, W1} per K tile on a ring of THREE
-// 48 KiB buffers, tile kt+2 staged in phase kt into the buffer read in phase kt-1 (same WAR/RAW argument), vmcnt(6) steady.
-// They exist for the tile schedule (build_schedule), which fills the last round of a launch in half-tile granules.
-template <int NSPLIT, int EPI>
+// 48 KiB buffers, tile kt+2 staged in phase kt into the buffer read in phase kt-1 (same WAR/RAW argument).  They close a
+// workgroup's list (build_schedule) and take no part in the cross-tile prefetch.
+template <typename T, int TERMS, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
-    VTQ_PP_COMMON()
-#define VTQ_SYNC_OPEN(n_dma)                                   \
-    wait_dma(n_dma);                                           \
+    typedef typename Vec<T>::x8 tx8;
+    constexpr int BK = (TERMS == 1) ? 64 : 32;
+    constexpr int ROWB = BK * 2;
+    constexpr int APL = (TERMS == 1) ? 1 : 2;        // activation planes (also the planes of a 16-bit output)
+    constexpr int REG_B = 16384;                     // one half-tile region (A: all planes; W with one plane of BK = 32 fills half)
+    constexpr int BUF_B = 4 * REG_B;                 // one K tile: regions 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
+    constexpr int NA = 2, NW = (TERMS == 2) ? 1 : 2; // LDS-DMA instructions per wave per A / W region
+    constexpr int GE = NA + 2 * NW, GO = NA;
+    constexpr int NFA = 8, NFB = (TERMS == 2) ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntn = p.N / 256;
+    const int nkt = p.K / BK;
+    // Per-lane addressing state.  It is RE-DERIVED at the top of every tile (tile_setup) from an opaque copy of the thread id,
+    // so that none of it stays live across the epilogue, whose accumulators + staging values already fill the register file.
+    int tid, fr, fq;
+    uint32_t a_off[2], w_off[2];     // DMA source byte offsets inside a half-tile plane (two rounds of 512 x 16 B; 2 planes: one round each)
+    int a_rd[2], b_rd[2];            // fragment read offsets inside a region: x = k-step (TERMS 1) or plane (TERMS 2, 3)
+    auto tile_setup = [&]() {
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        fr = lane & 15;
+        fq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if constexpr (TERMS == 1) {
+                const int slot = r * 512 + tid;
+                const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);
+                a_off[r] = (uint32_t)(row * p.lda + c * 8) * 2u;
+                w_off[r] = (uint32_t)(row * p.K + c * 8) * 2u;
+            } else {
+                const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);
+                a_off[r] = (uint32_t)(row * p.lda + c * 8) * 2u;
+                w_off[r] = (uint32_t)(row * p.K + c * 8) * 2u;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if constexpr (TERMS == 1) {
+                const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;
+                a_rd[x] = (wr * 64 + fr) * ROWB + ch;
+                b_rd[x] = (wc * 32 + fr) * ROWB + ch;
+            } else {
+                const int ch = (fq ^ swz<32>(fr)) << 4;
+                a_rd[x] = x * 8192 + (wr * 64 + fr) * ROWB + ch;
+                b_rd[x] = x * 8192 + (wc * 32 + fr) * ROWB + ch;
+            }
+        }
+    };
+    // plane strides in bytes (wave-uniform: they go on the scalar base of a DMA, the per-lane part stays 32 bit)
+    const int64_t a_pl = (TERMS == 1) ? 0 : p.a_plane * 2, w_pl = (TERMS == 3) ? p.w_plane * 2 : 0;
+    f32x4 acc[2][2][4][2];
+    tx8 fa[NFA], fb0[NFB], fb1[NFB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto read_a = [&](const char* reg) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const tx8*)(reg + a_rd[x] + i * 16 * ROWB);
+    };
+    auto read_b = [&](const char* reg, tx8(&fb)[NFB]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (TERMS == 2) fb[j] = *(const tx8*)(reg + b_rd[0] + j * 16 * ROWB);
+            else {
+#pragma unroll
+                for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const tx8*)(reg + b_rd[x] + j * 16 * ROWB);
+            }
+        }
+    };
+    auto mma = [&](f32x4(&c)[4][2], const tx8(&fb)[NFB]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (TERMS == 1) {
+                    c[i][j] = mfma16<T>(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j]);
+                    c[i][j] = mfma16<T>(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j]);
+                } else if constexpr (TERMS == 2) {
+                    c[i][j] = mfma16<T>(fb[j], fa[i * 2 + 0], c[i][j]);
+                    c[i][j] = mfma16<T>(fb[j], fa[i * 2 + 1], c[i][j]);
+                } else {
+                    c[i][j] = mfma16<T>(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j]);
+                    c[i][j] = mfma16<T>(fb[j * 2 + 0], fa[i * 2 + 1], c[i][j]);
+                    c[i][j] = mfma16<T>(fb[j * 2 + 1], fa[i * 2 + 0], c[i][j]);
+                }
+            }
+    };
+    // stage region r (0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1) of K tile kt of the tile with bases (ag, wg)
+    auto stage = [&](const T* ag, const T* wg, int kt, int r) {
+        char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
+        const bool isA = (r == 0 || r == 3);
+        const int half = (r >= 2) ? 1 : 0;
+        if (isA) {
+            const char* base = (const char*)(ag + (int64_t)half * kHalfRows * p.lda + kt * BK);
+            glds16(base + a_off[0], dst);
+            glds16(base + a_pl + a_off[1], dst + 8192);
+        } else {
+            const char* base = (const char*)(wg + (int64_t)half * kHalfRows * p.K + kt * BK);
+            glds16(base + w_off[0], dst);
+            if constexpr (NW == 2) glds16(base + w_pl + w_off[1], dst + 8192);
+        }
+    };
+
+#define VTQ_SYNC_OPEN_WAITED()                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
     __builtin_amdgcn_sched_barrier(0);                         \
     __builtin_amdgcn_s_barrier();                              \
@@ -367,92 +392,179 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                              \
     __builtin_amdgcn_sched_barrier(0);
 
-    if (!tl.half) {
-        // ---- prologue: groups 0, 1, 2 ----------------------------------------------------------------------------
-        stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
-        if (nkt > 1) { stage(1, 0); stage(1, 1); stage(1, 2); }
-        wait_dma(nkt > 1 ? 8 : 2);
-        __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
+    constexpr int EOPS = epilogue_vmem_ops<APL, EPI, 2>();
+    constexpr int NCHAIN = (EOPS + GE > 63) ? 63 : EOPS + GE;   // youngest ops that may stay in flight while g0/g1 of a chained tile are waited for
+    constexpr bool kChain = (EPI != EPI_EMBED);                 // cross-tile DMA chaining (EMBED's stores are conditional: not countable)
+    // the schedule is read through the scalar cache (constant address space): a vector load here would make hipcc drain
+    // vmcnt -- i.e. the previous tile's epilogue stores -- at the top of every tile
+    const __attribute__((address_space(4))) int* sch = (const __attribute__((address_space(4))) int*)p.sched;
+    const int it_beg = sch[blockIdx.x], it_end = sch[blockIdx.x + 1];
+    bool chained = false;       // this tile's K tile 0 (both groups) was staged by the previous tile; K tile 1's g2 is still to issue
+    for (int it = it_beg; it < it_end; ++it) {
+        const int d = sch[it];
+        const int tile = d >> 2, kind = d & 3;
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int64_t m0 = (int64_t)tm * 256 + (kind == 2 ? kHalfRows : 0);
+        const int n0 = tn * 256;
+        const T* __restrict__ Ag = (const T*)p.A + m0 * p.lda;
+        const T* __restrict__ Wg = (const T*)p.W + (int64_t)n0 * p.K;
+        // the next entry of this workgroup's list, if the DMA ring may run on into it
+        const T* Agn = Ag;
+        const T* Wgn = Wg;
+        bool has_next = false;
+        if constexpr (kChain) {
+            if (kind == 0 && it + 1 < it_end && !(p.flags & GEMM_FLAG_NO_CHAIN)) {
+                const int dn = sch[it + 1];
+                if ((dn & 3) == 0) {
+                    const int tmn = (dn >> 2) / ntn, tnn = (dn >> 2) - tmn * ntn;
+                    Agn = (const T*)p.A + (int64_t)tmn * 256 * p.lda;
+                    Wgn = (const T*)p.W + (int64_t)tnn * 256 * p.K;
+                    has_next = true;
+                }
+            }
+        }
+        tile_setup();
+        zero_acc();
+        if (kind == 0) {
+            // ---- entry: groups 0, 1, 2 in flight, group 0 landed for everyone ------------------------------------------
+            if (!chained) {
+                stage(Ag, Wg, 0, 0); stage(Ag, Wg, 0, 1); stage(Ag, Wg, 0, 2); stage(Ag, Wg, 0, 3);
+                if (nkt > 1) { stage(Ag, Wg, 1, 0); stage(Ag, Wg, 1, 1); stage(Ag, Wg, 1, 2); wait_vm<GO + GE>(); }
+                else wait_vm<GO>();
+            } else {
+                // g0, g1 were issued during the previous tile's last K tile; its epilogue stores came after them; g2 now
+                stage(Ag, Wg, 1, 0); stage(Ag, Wg, 1, 1); stage(Ag, Wg, 1, 2);
+                if constexpr (kChain) wait_vm<NCHAIN>();             // g0 AND g1 landed: they are older than every epilogue op
+            }
+            __builtin_amdgcn_s_barrier();
+            if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
 
-        for (int kt = 0; kt < nkt; ++kt) {
-            const char* buf = smem + (kt & 1) * BUF_B;
-            // ---- phase A --------------------------------------------------------------------------------------------
-            read_b(buf + 1 * REG_B, fb0);
-            read_a(buf + 0 * REG_B);
-            read_b(buf + 2 * REG_B, fb1);
-            if (kt + 1 < nkt) stage(kt + 1, 3);
-            VTQ_SYNC_OPEN(kt + 1 < nkt ? 8 : 0)
-            mma(acc[0][0], fb0);
-            mma(acc[0][1], fb1);
-            VTQ_SYNC_CLOSE()
-            // ---- phase B --------------------------------------------------------------------------------------------
-            read_a(buf + 3 * REG_B);
-            if (kt + 2 < nkt) { stage(kt + 2, 0); stage(kt + 2, 1); stage(kt + 2, 2); }
-            VTQ_SYNC_OPEN(kt + 2 < nkt ? 8 : (kt + 1 < nkt ? 2 : 0))
-            mma(acc[1][1], fb1);
-            mma(acc[1][0], fb0);
-            VTQ_SYNC_CLOSE()
+            for (int kt = 0; kt < nkt; ++kt) {
+                const char* buf = smem + (kt & 1) * BUF_B;
+                // ---- phase A --------------------------------------------------------------------------------------------
+                read_b(buf + 1 * REG_B, fb0);
+                read_a(buf + 0 * REG_B);
+                read_b(buf + 2 * REG_B, fb1);
+                if (kt + 1 < nkt) {
+                    stage(Ag, Wg, kt + 1, 3);
+                    if (kt == 0 && chained) { if constexpr (kChain) wait_vm<63>(); }   // g1 was covered at entry; do not drain the stores
+                    else wait_vm<GE + GO>();
+                } else if (has_next) {
+                    stage(Agn, Wgn, 0, 3);                    // next tile's g1 (nkt is even: its K tile 0 lives in buffer 0)
+                    wait_vm<GE + GO>();
+                } else {
+                    wait_vm<0>();
+                }
+                VTQ_SYNC_OPEN_WAITED()
+                mma(acc[0][0], fb0);
+                mma(acc[0][1], fb1);
+                VTQ_SYNC_CLOSE()
+                // ---- phase B --------------------------------------------------------------------------------------------
+                read_a(buf + 3 * REG_B);
+                if (kt + 2 < nkt) {
+                    stage(Ag, Wg, kt + 2, 0); stage(Ag, Wg, kt + 2, 1); stage(Ag, Wg, kt + 2, 2);
+                    wait_vm<GO + GE>();
+                } else if (kt + 2 == nkt) {
+                    if (has_next) { stage(Agn, Wgn, 0, 0); stage(Agn, Wgn, 0, 1); stage(Agn, Wgn, 0, 2); wait_vm<GO + GE>(); }
+                    else wait_vm<GO>();
+                }                                             // last K tile: nothing of this tile is left to land
+                VTQ_SYNC_OPEN_WAITED()
+                mma(acc[1][1], fb1);
+                mma(acc[1][0], fb0);
+                VTQ_SYNC_CLOSE()
+            }
+            if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
+            if (!(p.flags & GEMM_FLAG_NO_EPILOGUE))
+                pp_epilogue<T, APL, EPI, 2>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+            else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
+            }
+            chained = has_next;
+            if (it + 1 < it_end) {                            // the staging images are re-staged / re-used next: retire their reads
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            constexpr int BUF_H = 3 * REG_B;
+            constexpr int GH = NA + 2 * NW;
+            auto stage_h = [&](int kt, int slot) {             // {A0, W0, W1} of K tile kt into ring slot
+                char* dst = smem + slot * BUF_H + wave * 1024;
+                const char* ab = (const char*)(Ag + kt * BK);
+                const char* w0 = (const char*)(Wg + kt * BK);
+                const char* w1 = (const char*)(Wg + (int64_t)kHalfRows * p.K + kt * BK);
+                glds16(ab + a_off[0], dst);
+                glds16(ab + a_pl + a_off[1], dst + 8192);
+                glds16(w0 + w_off[0], dst + REG_B);
+                if constexpr (NW == 2) glds16(w0 + w_pl + w_off[1], dst + REG_B + 8192);
+                glds16(w1 + w_off[0], dst + 2 * REG_B);
+                if constexpr (NW == 2) glds16(w1 + w_pl + w_off[1], dst + 2 * REG_B + 8192);
+            };
+            stage_h(0, 0);
+            if (nkt > 1) { stage_h(1, 1); wait_vm<GH>(); }
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (wr == 1) __builtin_amdgcn_s_barrier();
+            int slot = 0;                                      // kt % 3
+            for (int kt = 0; kt < nkt; ++kt) {
+                const char* buf = smem + slot * BUF_H;
+                read_b(buf + 1 * REG_B, fb0);
+                read_a(buf + 0 * REG_B);
+                read_b(buf + 2 * REG_B, fb1);
+                const int nslot = slot == 0 ? 2 : slot - 1;    // (kt + 2) % 3
+                if (kt + 2 < nkt) { stage_h(kt + 2, nslot); wait_vm<GH>(); }
+                else wait_vm<0>();
+                VTQ_SYNC_OPEN_WAITED()
+                mma(acc[0][0], fb0);
+                mma(acc[0][1], fb1);
+                VTQ_SYNC_CLOSE()
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            pp_epilogue<T, APL, EPI, 1>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+            chained = false;
+            if (it + 1 < it_end) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
-        if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
-        pp_epilogue<NSPLIT, EPI, 2>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
-    } else {
-        constexpr int BUF_H = 3 * REG_B;
-        auto stage_h = [&](int kt, int slot) {             // {A0, W0, W1} of K tile kt into ring slot
-            char* dst = smem + slot * BUF_H + wave * 1024;
-            const bf16* ab = Ag + kt * BK;
-            const bf16* w0 = Wg + kt * BK;
-            const bf16* w1 = Wg + (int64_t)128 * p.K + kt * BK;
-            glds16(ab + a_off[0], dst);
-            glds16(ab + a_off[1], dst + 8192);
-            glds16(w0 + w_off[0], dst + REG_B);
-            glds16(w0 + w_off[1], dst + REG_B + 8192);
-            glds16(w1 + w_off[0], dst + 2 * REG_B);
-            glds16(w1 + w_off[1], dst + 2 * REG_B + 8192);
-        };
-        stage_h(0, 0);
-        if (nkt > 1) stage_h(1, 1);
-        wait_dma(nkt > 1 ? 6 : 0);
-        __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();
-        int slot = 0;                                      // kt % 3
-        for (int kt = 0; kt < nkt; ++kt) {
-            const char* buf = smem + slot * BUF_H;
-            read_b(buf + 1 * REG_B, fb0);
-            read_a(buf + 0 * REG_B);
-            read_b(buf + 2 * REG_B, fb1);
-            const int nslot = slot == 0 ? 2 : slot - 1;    // (kt + 2) % 3
-            if (kt + 2 < nkt) stage_h(kt + 2, nslot);
-            VTQ_SYNC_OPEN(kt + 2 < nkt ? 6 : 0)
-            mma(acc[0][0], fb0);
-            mma(acc[0][1], fb1);
-            VTQ_SYNC_CLOSE()
-            slot = slot == 2 ? 0 : slot + 1;
-        }
-        if (wr == 0) __builtin_amdgcn_s_barrier();
-        pp_epilogue<NSPLIT, EPI, 1>(p, acc, smem, tid, wr, wc, fr, fq, m0, n0);
     }
-#undef VTQ_SYNC_OPEN
+#undef VTQ_SYNC_OPEN_WAITED
 #undef VTQ_SYNC_CLOSE
 }
 
 // =====================================================================================================================
-// Tile schedule (host).  Workgroups are dispatched in blockIdx order, round-robin over the 8 XCDs, one per CU (LDS-bound),
-// and a CU takes the next block when it retires one.  The schedule keeps each XCD on a contiguous run of tiles (A row panels
-// and W stay in its L2) and ends the run with 128-row HALF tiles, so the last round is filled in half-tile granules: N = 768
-// GEMMs are 1.5 rounds at 64 pairs, qkv 4.5 -- measured -10 % (out-proj), -6 % (fc2), -3 % (qkv) against whole tiles only.
-// The number of split tiles is chosen by simulating the greedy dispatch per XCD.  Output never depends on the schedule:
-// every element is accumulated over K in the same order in both tile forms.
-// (Starting half of the CUs on a half tile, to keep neighbours' epilogue write bursts out of phase, was measured too:
-//  no gain -- a write burst starves every CU's operand stream, not only the writers'.)
-constexpr int kXcds = 8, kCusPerXcd = 32;
-constexpr double kHalfCost = 0.57;              // measured: a launch of half tiles only takes 1.14x the whole-tile launch
+// Tile schedule (host).  The launch is PERSISTENT: kNumCus workgroups, dealt round-robin over the 8 XCDs by the dispatcher
+// (workgroup b lands on XCD b % 8, one per CU: 144 KiB of LDS each), every workgroup walks its own list.
+//   * XCD x owns a contiguous run of the row-major tile order (its A row panels stay in its L2).
+//   * Inside the run the order is column-group-major: (column group of cg tiles) > row panel > column.  The XCD's 32
+//     workgroups take consecutive entries, so at any time they work on 32/cg row panels x cg column tiles, and the cg W tiles
+//     (cg * 256 * K * planes * 2 B, sized to ~2.5 MiB) stay L2-resident while the panels stream past.
+//   * The run ENDS with 128x256 half tiles, so the last round is filled in half-tile granules; how many tiles to split is
+//     chosen by simulating the greedy list assignment (half tile = 0.57 of a tile, measured).
+//   * Entries are dealt to the XCD's workgroups in order, each to the least loaded one (what a dynamic queue would do with
+//     these costs).  Output never depends on the schedule: every element is accumulated over K in the same order in both
+//     tile forms, so results are bitwise independent of batch size and placement.
+constexpr int kXcds = 8, kCusPerXcd = 32, kNumCus = kXcds * kCusPerXcd;
+constexpr double kHalfCost = 0.57;
+
+int cus_per_xcd() {
+    static const int n = [] { const char* v = getenv("VTQ_GEMM_CUS"); const int k = v ? atoi(v) : kCusPerXcd; return (k >= 1 && k <= kCusPerXcd) ? k : kCusPerXcd; }();
+    return n;                                    // measurement knob: workgroups per XCD of the persistent launch (default: all 32 CUs)
+}
 
 double greedy_makespan(int n_full, int n_half) {
     double cu[kCusPerXcd] = {0};
+    const int ncu = cus_per_xcd();
     auto put = [&](double d) {
         int best = 0;
-        for (int i = 1; i < kCusPerXcd; ++i) if (cu[i] < cu[best]) best = i;
+        for (int i = 1; i < ncu; ++i) if (cu[i] < cu[best]) best = i;
         cu[best] += d;
     };
     for (int i = 0; i < n_full; ++i) put(1.0);
@@ -462,7 +574,7 @@ double greedy_makespan(int n_full, int n_half) {
     return m;
 }
 
-// sequence of one XCD owning tiles [t0, t0 + cnt): whole tiles, then `tail` tiles as top/bottom halves
+// entries of one XCD owning `order[0..cnt)`: whole tiles, then `tail` tiles as top/bottom halves
 void xcd_sequence(const int* order, int cnt, std::vector<int>& out) {
     static const bool all_halves = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return v && v[0] == '2'; }();   // measurement knob
     int best_tail = 0;
@@ -476,78 +588,156 @@ void xcd_sequence(const int* order, int cnt, std::vector<int>& out) {
     for (int i = cnt - best_tail; i < cnt; ++i) { out.push_back((order[i] << 2) | 1); out.push_back((order[i] << 2) | 2); }
 }
 
-std::vector<int> build_schedule(int ntm, int ntn) {
+// -> [offsets (kNumCus + 1 entries, absolute indices into the same array)] [entries: (tile << 2) | kind]
+std::vector<int> build_schedule(int ntm, int ntn, int cg) {
     const int nt = ntm * ntn, q = nt / kXcds, r = nt % kXcds;
-    // tile order the XCD runs are cut from: row-major, i.e. the column tiles of one A row panel are neighbours.  (Cutting the
-    // runs from column BANDS of 3 / 4 / 6 tiles instead -- fewer distinct W tiles per XCD round -- measured no different.)
-    std::vector<int> order(nt);
-    for (int i = 0; i < nt; ++i) order[i] = i;
-    std::vector<std::vector<int>> seq(kXcds);
-    size_t total = 0;
+    if (cg < 1) cg = 1;
+    std::vector<std::vector<int>> lists(kNumCus);
     for (int x = 0; x < kXcds; ++x) {
-        const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-        xcd_sequence(order.data() + t0, q + (x < r ? 1 : 0), seq[x]);
-        total += seq[x].size();
+        const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+        std::vector<std::tuple<int, int, int, int>> keyed;       // (column group, row panel, column, tile)
+        keyed.reserve(cnt);
+        for (int t = t0; t < t0 + cnt; ++t) keyed.emplace_back((t % ntn) / cg, t / ntn, t % ntn, t);
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<int> order(cnt), seq;
+        for (int i = 0; i < cnt; ++i) order[i] = std::get<3>(keyed[i]);
+        xcd_sequence(order.data(), cnt, seq);
+        double load[kCusPerXcd] = {0};
+        const int ncu = cus_per_xcd();
+        for (int e : seq) {
+            int best = 0;
+            for (int i = 1; i < ncu; ++i) if (load[i] < load[best] - 1e-9) best = i;
+            load[best] += (e & 3) ? kHalfCost : 1.0;
+            lists[x + kXcds * best].push_back(e);
+        }
     }
-    std::vector<int> out;
-    out.reserve(total);
-    for (size_t j = 0; out.size() < total; ++j)             // block b -> XCD b % 8 while every XCD still has entries
-        for (int x = 0; x < kXcds; ++x)
-            if (j < seq[x].size()) out.push_back(seq[x][j]);
+    std::vector<int> out(kNumCus + 1);
+    int off = kNumCus + 1;
+    for (int b = 0; b < kNumCus; ++b) { out[b] = off; off += (int)lists[b].size(); }
+    out[kNumCus] = off;
+    for (int b = 0; b < kNumCus; ++b) out.insert(out.end(), lists[b].begin(), lists[b].end());
     return out;
 }
 
-struct DevSched { int* dev; int n; };
-// process-wide cache keyed by the tile grid; entries are a few KiB and live until exit
-hipError_t schedule_for(int ntm, int ntn, DevSched& ds) {
+// Measurement form (GEMM_FLAG_DYNAMIC): the same per-XCD sequences, but one entry per workgroup in hardware dispatch order
+// (block b -> XCD b % 8): offsets[b] = first entry of block b, one entry each.
+std::vector<int> build_schedule_dynamic(int ntm, int ntn, int cg) {
+    const int nt = ntm * ntn, q = nt / kXcds, r = nt % kXcds;
+    if (cg < 1) cg = 1;
+    std::vector<std::vector<int>> seq(kXcds);
+    size_t total = 0;
+    for (int x = 0; x < kXcds; ++x) {
+        const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+        std::vector<std::tuple<int, int, int, int>> keyed;
+        for (int t = t0; t < t0 + cnt; ++t) keyed.emplace_back((t % ntn) / cg, t / ntn, t % ntn, t);
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<int> order(cnt);
+        for (int i = 0; i < cnt; ++i) order[i] = std::get<3>(keyed[i]);
+        xcd_sequence(order.data(), cnt, seq[x]);
+        total += seq[x].size();
+    }
+    std::vector<int> ent;
+    for (size_t j = 0; ent.size() < total; ++j)
+        for (int x = 0; x < kXcds; ++x)
+            if (j < seq[x].size()) ent.push_back(seq[x][j]);
+    std::vector<int> out(total + 1);
+    for (size_t b = 0; b <= total; ++b) out[b] = (int)(total + 1 + b);
+    out.insert(out.end(), ent.begin(), ent.end());
+    return out;
+}
+
+int column_group(int ntn, int K, int wpl) {
+    const double tile_bytes = 256.0 * K * 2.0 * wpl;
+    int cg = (int)(2.5 * 1048576.0 / tile_bytes);
+    if (cg < 1) cg = 1;
+    if (cg >= ntn || ntn <= 4) cg = ntn;
+    return cg;
+}
+
+// Device-resident schedules, per DEVICE (a second engine on another GPU of the same process gets its own copies) and per
+// (tile grid, column group); entries are a few KiB and live until exit.
+struct DevSched { int* dev; int nwg; };
+hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds) {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, DevSched> cache;
+    static std::map<std::tuple<int, int, int, int, int>, DevSched> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find({ntm, ntn});
+    const auto key = std::make_tuple(dev, ntm, ntn, cg, (int)dynamic);
+    auto it = cache.find(key);
     if (it != cache.end()) { ds = it->second; return hipSuccess; }
-    const std::vector<int> h = build_schedule(ntm, ntn);
-    DevSched d{nullptr, (int)h.size()};
-    hipError_t e = hipMalloc(&d.dev, h.size() * sizeof(int));
+    const std::vector<int> h = dynamic ? build_schedule_dynamic(ntm, ntn, cg) : build_schedule(ntm, ntn, cg);
+    DevSched d{nullptr, dynamic ? h[0] - 1 : kXcds * cus_per_xcd()};
+    e = hipMalloc(&d.dev, h.size() * sizeof(int));
     if (e != hipSuccess) return e;
     e = hipMemcpy(d.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);     // blocking; first launch of a shape only
     if (e != hipSuccess) return e;
-    cache[{ntm, ntn}] = d;
+    cache[key] = d;
     ds = d;
     return hipSuccess;
 }
 
-template <int NSPLIT, int EPI> hipError_t launch_t(GemmArgs a, hipStream_t s) {
+int env_flags() {
+    static const int f = [] { const char* v = getenv("VTQ_GEMM_FLAGS"); return v ? atoi(v) : 0; }();   // measurement knobs (kernels.h)
+    return f;
+}
+
+template <typename T, int TERMS, int EPI> hipError_t launch_t(GemmArgs a, hipStream_t s) {
     constexpr int LDS = 147456;                    // full tiles: DMA ring 128 KiB, epilogue images 256x528 B; half tiles: 3 x 48 KiB
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_pp2_kernel<NSPLIT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
+    static std::mutex mu;
+    static bool configured[64] = {false};          // hipFuncSetAttribute is per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            e = hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, TERMS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
     }
-    static const bool use_sched = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return !(v && v[0] == '0'); }();
-    int nwg = (a.M / 256) * (a.N / 256);
-    a.sched = nullptr;
-    if (use_sched) {
-        DevSched ds;
-        hipError_t e = schedule_for(a.M / 256, a.N / 256, ds);
-        if (e != hipSuccess) return e;
-        a.sched = ds.dev;
-        nwg = ds.n;
-    }
-    hipLaunchKernelGGL((gemm_pp2_kernel<NSPLIT, EPI>), dim3(nwg), dim3(512), LDS, s, a);
+    constexpr int WPL = (TERMS == 3) ? 2 : 1;
+    DevSched ds;
+    a.flags = env_flags();
+    int cg = column_group(a.N / 256, a.K, WPL);
+    if (const char* v = getenv("VTQ_GEMM_CG")) cg = atoi(v);           // measurement knob: column-group width of the tile order
+    e = schedule_for(a.M / 256, a.N / 256, cg, (a.flags & GEMM_FLAG_DYNAMIC) != 0, ds);
+    if (e != hipSuccess) return e;
+    a.sched = ds.dev;
+    hipLaunchKernelGGL((gemm_pp2_kernel<T, TERMS, EPI>), dim3(ds.nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
+}
+
+template <typename T, int TERMS> hipError_t launch_e(const GemmArgs& a, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case EPI_BIAS: return launch_t<T, TERMS, EPI_BIAS>(a, s);
+        case EPI_BIAS_GELU: return launch_t<T, TERMS, EPI_BIAS_GELU>(a, s);
+        case EPI_RESID: return launch_t<T, TERMS, EPI_RESID>(a, s);
+        case EPI_EMBED: return launch_t<T, TERMS, EPI_EMBED>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-std::vector<int> gemm_tile_schedule(int ntm, int ntn) { return build_schedule(ntm, ntn); }
+std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
+    return build_schedule(ntm, ntn, column_group(ntn, K, wpl));
+}
 
-hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s) {
-    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K % 64 || a.lda % 8 || (nsplit != 1 && nsplit != 3)) return hipErrorInvalidValue;
-#define VTQ_CASE(NS, EP) if (nsplit == NS && epilogue == EP) return launch_t<NS, EP>(a, s);
-    VTQ_CASE(1, EPI_BIAS) VTQ_CASE(1, EPI_BIAS_GELU) VTQ_CASE(1, EPI_RESID) VTQ_CASE(1, EPI_EMBED)
-    VTQ_CASE(3, EPI_BIAS) VTQ_CASE(3, EPI_BIAS_GELU) VTQ_CASE(3, EPI_RESID) VTQ_CASE(3, EPI_EMBED)
-#undef VTQ_CASE
+hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) {
+    const int bk2 = (num.terms == 1) ? 128 : 64;         // two K tiles: the DMA ring's buffer parity is fixed across tiles
+    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K <= 0 || a.K % bk2 || a.lda % 8) return hipErrorInvalidValue;
+    if (!num.f16) {
+        if (num.terms == 1) return launch_e<bf16, 1>(a, epilogue, s);
+        if (num.terms == 3) return launch_e<bf16, 3>(a, epilogue, s);
+    } else {
+        if (num.terms == 1) return launch_e<f16, 1>(a, epilogue, s);
+        if (num.terms == 2) return launch_e<f16, 2>(a, epilogue, s);
+        if (num.terms == 3) return launch_e<f16, 3>(a, epilogue, s);
+    }
     return hipErrorInvalidValue;
 }
 

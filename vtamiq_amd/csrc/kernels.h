@@ -9,6 +9,25 @@ namespace vtq {
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
 
+// Operand format of a dense contraction: element type and MFMAs per product.
+//   terms 1: a*w (one 16-bit plane each);  2: (a_hi + a_lo)*w (activation hi/lo planes, single weight plane);
+//   terms 3: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (hi/lo planes for both).  ABI code (include/vtamiq_hip.h): terms | (f16 ? 16 : 0).
+struct Num {
+    int f16;      // 0 = bf16 planes, 1 = fp16 planes
+    int terms;    // 1 | 2 | 3
+    int apl() const { return terms == 1 ? 1 : 2; }     // planes of an activation tensor
+    int wpl() const { return terms == 3 ? 2 : 1; }     // planes of a weight tensor
+};
+inline Num num_from_code(int code) { return Num{(code >> 4) & 1, code & 15}; }
+inline bool num_valid(Num n) { return (n.terms == 1 || n.terms == 3 || (n.terms == 2 && n.f16)) && (n.f16 == 0 || n.f16 == 1); }
+
+// GemmArgs::flags, measurement knobs (environment VTQ_GEMM_FLAGS, read once per process)
+enum { GEMM_FLAG_WRAP_ROWS = 1,     // every tile writes the rows of row panel 0: no HBM write stream (timing experiments only)
+       GEMM_FLAG_NO_CHAIN = 2,      // no DMA chaining across a workgroup's consecutive tiles
+       GEMM_FLAG_DYNAMIC = 4,       // one schedule entry per workgroup, as many workgroups as entries (hardware dispatch order
+                                    // instead of the persistent lists): the round-1 launch form, for A/B timing
+       GEMM_FLAG_NO_EPILOGUE = 8 }; // skip the epilogue (timing experiments only: output is not written)
+
 // Where the sequences live in the row-major activation buffers: sequence s starts at row s*pitch + (s/per)*gap -- `per`
 // sequences per part-batch, each part-batch padded by `gap` rows to a multiple of 256 (the GEMM tile height).
 struct SeqMap { int pitch, per, gap; };
@@ -17,7 +36,7 @@ __host__ __device__ inline int64_t seq_row(const SeqMap& m, int s) { return (int
 struct GemmArgs {
     const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
     const void* W; int64_t w_plane;               // bf16 planes [N, K]
-    int M, N, K;                                  // M % 256 == 0, N % 256 == 0, K % 64 == 0
+    int M, N, K;                                  // M % 256 == 0, N % 256 == 0, K % 128 == 0 (terms 1) | K % 64 == 0
     const float* bias;                            // [N]
     const float* gamma;                           // [N] or nullptr (EPI_RESID)
     float* x;                                     // fp32 [*, N]: EPI_RESID in/out, EPI_EMBED out
@@ -25,32 +44,37 @@ struct GemmArgs {
     const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
     const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
     const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
-    const int* sched;                             // set by launch_gemm: tile schedule (gemm.hip build_schedule) or nullptr
+    const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
+    int flags;                                    // set by launch_gemm: GEMM_FLAG_*
 };
 
-hipError_t launch_gemm(const GemmArgs& a, int nsplit, int epilogue, hipStream_t s);
-// block order of a (ntm x ntn)-tile GEMM: entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half (host only)
-std::vector<int> gemm_tile_schedule(int ntm, int ntn);
+hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
+// Persistent schedule of a (ntm x ntn)-tile GEMM with K columns and wpl weight planes (host only): 257 offsets, then the
+// per-workgroup lists; entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half
+std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
 
-hipError_t launch_split_bf16(const float* src, void* dst, int64_t plane, int64_t numel, int nsplit, hipStream_t s);
+// fp32 -> 16-bit planes (f16: 0 = bf16, 1 = fp16; planes: 1 = single, 2 = hi + lo with lo `plane` elements behind hi)
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s);
 
-// nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> bf16 planes [rows_pad, K], rows >= nimg*B*N zero-filled
-hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int nsplit,
-                               hipStream_t s);
+// nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> 16-bit planes [rows_pad, K], rows >= nimg*B*N zero-filled
+hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16,
+                               int planes, hipStream_t s);
 
-// per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1)
+// per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1);
+// positions outside [0, 1) are clamped into the table and flagged in *err (bit 0)
 hipError_t launch_embed_index(const float* const* pos, const float* const* sc, int nimg, int* pidx, int* sidx, int* row_map, int B, int N,
-                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, hipStream_t s);
+                              int rows_pad, SeqMap sm, int T, int grid, int num_scales, int* err, hipStream_t s);
 
 // CLS (+pos row 0) and register tokens into the first T rows of every sequence
 hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, SeqMap sm,
                          int T, int H, hipStream_t s);
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int nsplit, hipStream_t s);
+                            int f16, int planes, hipStream_t s);
 
+// num.terms: 1 = single planes, 3 = hi/lo planes for Q, K, V and P (the 2-term form is not offered: DESIGN.md section 2)
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            int nsplit, hipStream_t s);
+                            Num num, hipStream_t s);
 
 // zero the rows of the residual stream that belong to no token: per-sequence pads, per-part tails, and everything up to rows_total
 hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s);
@@ -75,11 +99,14 @@ hipError_t launch_fold_ca(const float* Wc, const float* bc, const float* Wd, con
 // ---- CLS-only tail of the last encoder layer (cls_tail.hip) -----------------------------------------------------------
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
                           hipStream_t s);
-// y[r][n] = epi(W[n] . x[r] + bias[n]) with W as bf16 planes; epi 0 plain, 1 GELU, 2 res[r][n] + gamma[n] * v
-hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int nsplit, const float* bias, const float* gamma,
+// y[r][n] = epi(W[n] . x[r] + bias[n]) with W as 16-bit planes (f16, wplanes); epi 0 plain, 1 GELU, 2 res[r][n] + gamma[n] * v
+hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int f16, int wplanes, const float* bias, const float* gamma,
                               const float* res, float* y, int R, int N, int K, int epi, hipStream_t s);
+// K, V rows of the packed qkv planes (f16, planes); any S (the score buffer is dynamic LDS)
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int nsplit, hipStream_t s);
+                                int f16, int planes, hipStream_t s);
+// largest S launch_cls_attention accepts (LDS score buffer); longer sequences run the full last layer instead
+int cls_attention_max_seq();
 
 // ---- on-device image -> patch tensor (patches.hip) -------------------------------------------------------
 hipError_t launch_image_normalize(const uint8_t* in, float* out, int NI, int H, int W, const int* flips, const float* mean, const float* sd,

@@ -21,7 +21,8 @@ from torch import nn
 from . import _lib
 from .spec import ModelSpec, make_spec
 
-_PRECISIONS = {"bf16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3}
+_PRECISIONS = _lib.PRECISIONS
+DEFAULT_PRECISION = "fp16x3"
 
 
 class _Params(nn.Module):
@@ -136,6 +137,9 @@ class VTAMIQ(nn.Module):
         for k, v in kwargs.items():         # reference only warns about unknown kwargs (vtamiq.py:49)
             warnings.warn(f"[VTAMIQ] Unused kwarg [{k}={v}]")
         vit_config = dict(vit_config or {})
+        # backbone.py:25: `pretrained` defaults to True; transformer.py:621-624 then np.load()s config["vit_weights_path"]
+        pretrained = bool(vit_config.get("pretrained", True))
+        weights_path = vit_config.pop("vit_weights_path", None)
         self.spec = make_spec(vit_config, calibrate=calibrate, diff_scale=diff_scale, num_rgs=num_rgs,
                               num_rcabs=num_rcabs, ca_reduction=ca_reduction)
         spec = self.spec
@@ -153,7 +157,7 @@ class VTAMIQ(nn.Module):
         self.q_predictor = nn.Sequential(nn.Identity(), nn.Linear(H, H // 4), nn.PReLU(), nn.Identity(),
                                          nn.Linear(H // 4, 1))              # vtamiq.py:71-77 (Dropout slots 0 and 3)
         self.return_features = return_features
-        precision = precision or os.environ.get("VTAMIQ_PRECISION", "bf16x3")
+        precision = precision or os.environ.get("VTAMIQ_PRECISION", DEFAULT_PRECISION)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -161,6 +165,21 @@ class VTAMIQ(nn.Module):
         self._engine_device = None
         self._weights_sig = None
         self._warned_grad = False
+        # VTAMIQ_VALIDATE_INPUTS=1 (or model.validate_inputs = True): synchronise after every forward and raise IndexError when a
+        # position lay outside [0, 1), as the reference's table lookup does (transformer.py:417-421).  Off by default: the
+        # forward stays asynchronous and such an index is clamped into the table (never read out of bounds); check_inputs()
+        # reports it on demand.
+        self.validate_inputs = os.environ.get("VTAMIQ_VALIDATE_INPUTS", "0") == "1"
+        if pretrained:
+            from .weights import default_vit_weights_path, load_vit_npz
+            path = weights_path or os.environ.get("VTAMIQ_VIT_WEIGHTS") or default_vit_weights_path(self.spec.variant)
+            if os.path.exists(path):
+                print("ViT: Loading pretrained transformer from path:", path)          # transformer.py:623
+                load_vit_npz(self, path)
+            else:
+                warnings.warn(f"[VTAMIQ] pretrained=True but '{path}' does not exist: the transformer keeps its random "
+                              "initialisation (the reference raises FileNotFoundError here, transformer.py:622-624); pass "
+                              "vit_config['pretrained']=False, vit_config['vit_weights_path'] or load a checkpoint")
 
     # ---- reference surface --------------------------------------------------------------------------------
     @property
@@ -221,8 +240,22 @@ class VTAMIQ(nn.Module):
             pass
 
     def refresh_weights(self):
-        """Force a re-pack of the parameters into the engine on the next forward."""
+        """Force a re-pack of the parameters into the engine on the next forward.  REQUIRED after in-place edits through
+        `.data` (p.data.copy_(), p.data.normal_(), ...): those do not bump the version counter `_signature` watches, so the
+        engine would keep serving the previously packed weights.  load_state_dict / .to() / optimizer-style in-place ops on
+        the parameters themselves are picked up automatically; weights.load_* call this for you."""
         self._weights_sig = None
+
+    def check_inputs(self):
+        """Synchronise and raise IndexError if any forward since the last check saw a position outside [0, 1)."""
+        if self._engine is None:
+            return
+        flags = C.c_int32(0)
+        with torch.cuda.device(self._engine_device):
+            stream = torch.cuda.current_stream(self._engine_device).cuda_stream
+            _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
+        if flags.value & 1:
+            raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
 
     def _ensure_engine(self, device: torch.device):
         lib = _lib.load()
@@ -318,6 +351,8 @@ class VTAMIQ(nn.Module):
             finally:
                 if _trace is not None:
                     lib.vtq_set_token_trace(self._engine, None)
+        if self.validate_inputs:
+            self.check_inputs()
         return q, None
 
     def forward_pairwise(self, patches, pos, scales):
@@ -352,6 +387,8 @@ class VTAMIQ(nn.Module):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.vtq_forward_pairwise(self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N,
                                                 q.data_ptr(), stream))
+        if self.validate_inputs:
+            self.check_inputs()
         return q[:B], q[B:]
 
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------

@@ -31,6 +31,20 @@ def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: O
         raise ValueError("scale_ids are required when num_scales > 1")
     if not 1 <= num_scales <= 4:
         raise ValueError("1 <= num_scales <= 4")
+    # Range checks the reference gets for free from numpy fancy-indexing (an out-of-range patch raises IndexError there); the
+    # gather kernel itself does not bounds-check.  One small reduction + sync per call, on the loader side of the pipeline.
+    if (H >> (num_scales - 1)) < 16 or (W >> (num_scales - 1)) < 16:
+        raise ValueError(f"pyramid level {num_scales - 1} of a {H}x{W} image is smaller than one 16x16 patch")
+    smp = samples.to(torch.int64)
+    lvl = scale_ids.to(device=smp.device, dtype=torch.int64) if scale_ids is not None else torch.zeros(smp.shape[:2], dtype=torch.int64, device=smp.device)
+    if tuple(lvl.shape) != (NI, N):
+        raise ValueError("scale_ids must be int32 [NI, N]")
+    if bool(((lvl < 0) | (lvl >= num_scales)).any()):
+        raise IndexError("scale_ids outside [0, num_scales)")
+    hmax = torch.tensor([(H >> s) - 16 for s in range(num_scales)], device=smp.device)[lvl]
+    wmax = torch.tensor([(W >> s) - 16 for s in range(num_scales)], device=smp.device)[lvl]
+    if bool(((smp[..., 0] < 0) | (smp[..., 0] > hmax) | (smp[..., 1] < 0) | (smp[..., 1] > wmax)).any()):
+        raise IndexError("patch sample outside its pyramid level (row in [0, h-16], col in [0, w-16] required)")
     images_u8 = images_u8.contiguous()
     samples = samples.to(device=dev, dtype=torch.int32).contiguous()
     sid = scale_ids.to(device=dev, dtype=torch.int32).contiguous() if scale_ids is not None else None

@@ -18,6 +18,15 @@ import torch
 
 MODEL_STATE_DICT = "model_state_dict"          # train_config.py:53
 
+# transformer.py:68-98: where the reference looks for the JAX checkpoints (relative to the working directory)
+_VIT_WEIGHTS = {"ViT-B16": "./modules/VisionTransformer/weights/imagenet21k+imagenet2012_ViT-B_16.npz",
+                "ViT-B8": "./modules/VisionTransformer/weights/imagenet21k+imagenet2012_ViT-B_8.npz",
+                "ViT-L16": "./modules/VisionTransformer/weights/imagenet21k+imagenet2012_ViT-L_16.npz"}
+
+
+def default_vit_weights_path(variant: str) -> str:
+    return _VIT_WEIGHTS[variant]
+
 _ROOT = "Transformer/encoderblock_{}"
 _ATT = "MultiHeadDotProductAttention_1"
 
@@ -89,6 +98,7 @@ def load_vit_npz(model, npz) -> None:
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if unexpected:
         raise RuntimeError(f"unexpected keys from the ViT checkpoint: {unexpected[:4]}")
+    model.refresh_weights()
 
 
 def load_checkpoint(model, checkpoint, allow_vit: bool = True, allow_head: bool = True, map_location="cpu") -> Optional[dict]:
@@ -111,4 +121,5 @@ def load_checkpoint(model, checkpoint, allow_vit: bool = True, allow_head: bool 
     except RuntimeError as err:                                                    # modules/utils.py:84-91
         warnings.warn(f"{err}\nContinuing with partial load...")
         model.load_state_dict(sd, strict=False)
+    model.refresh_weights()
     return ckpt
