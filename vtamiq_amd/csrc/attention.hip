@@ -14,8 +14,8 @@
 //   * K tile chunks are XOR-swizzled ((row>>1)&7) for conflict-free ds_read_b128; V tile 64-byte halves are swapped on
 //     rows with bit 1 set so the four rows of a transposed read hit disjoint banks;
 //   * NSPLIT == 3: Q,K,V,P are hi/lo 16-bit pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
-//   * T = bf16 | f16 operand planes.  P (in (0, 1]) is split with a TRUNCATED hi part, so that lo = v - hi is exact in fp32 and
-//     costs one subtract and half a packed convert: f16: v_cvt_pkrtz + v_fma_mix per element; bf16: mask + subtract.
+//   * T = bf16 | f16 operand planes.  P (in (0, 1]) is split with a TRUNCATED hi part, so that lo = v - hi is exact in fp32:
+//     f16: v_cvt_pkrtz for a pair (subnormal results are kept: tools/micro/split_probe.hip); bf16: mask + subtract.
 #include <cstdlib>
 #include <mutex>
 
@@ -35,15 +35,16 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 template <typename T>
 __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x8& hi, typename Vec<T>::x8& lo) {
     if constexpr (std::is_same<T, f16>::value) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
         uint32_t hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]);      // truncation: hi <= p, p - hi exact
+            const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]);      // truncation: hi <= p, p - hi exact in fp32
+            const h2 hh = __builtin_bit_cast(h2, hp);
             hw[j] = __builtin_bit_cast(uint32_t, hp);
-            float r0, r1;
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw[j]), "v"(p[2 * j]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw[j]), "v"(p[2 * j + 1]));
-            lw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+            // plain C++ (v_cvt_f32_f16 + v_sub): an inline-asm v_fma_mix here read v_exp results inside the hardware's
+            // trans -> VALU forwarding window, which hipcc does not pad for asm operands: rare wrong lo halves (measured)
+            lw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p[2 * j] - (float)hh[0], p[2 * j + 1] - (float)hh[1]));
         }
         typedef __attribute__((ext_vector_type(4))) uint32_t u4;
         hi = __builtin_bit_cast(f16x8, u4{hw[0], hw[1], hw[2], hw[3]});
@@ -181,11 +182,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                                              // raw (unscaled) running max
-        // f16 planes: P is kept as 2^12 * exp(s - m) in (0, 4096], so that the lo half of its split (2^-11 of the value) stays a
-        // NORMAL f16 down to p = 3e-5 of the row maximum (v_cvt_pkrtz_f16_f32 flushes subnormal results); the row sum carries
-        // the same factor and it cancels in O / l.
-        constexpr float kPExp = std::is_same<T, f16>::value ? 12.0f : 0.0f;
-        const float nm = kPExp - m_new * sc;
+        const float nm = -m_new * sc;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)

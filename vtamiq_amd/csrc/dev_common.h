@@ -53,8 +53,12 @@ __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 
 // hi = RNE(v); lo = RNE(v - hi): v ~= hi + lo to ~16 (bf16) / ~22 (f16) significand bits.  f16 subnormals are kept by the
 // conversion and by the MFMA (tools/micro/f16_probe.hip), so no pre-scaling is needed for small values.
+// The value is made opaque first: with fp contraction hipcc otherwise forms hi twice -- once from the fp32-rounded v (the copy
+// that is stored) and once fused with the producing multiply (v_fma_mixlo_f16 on the exact product, the copy lo is taken
+// against); at f16 ties the two differ by one ulp and lo gets the wrong sign (measured: 1e-5 of attention outputs off by an ulp).
 template <typename T>
 __device__ __forceinline__ void split2(float v, T& hi, T& lo) {
+    asm volatile("" : "+v"(v));
     hi = (T)v;
     lo = (T)(v - (float)hi);
 }
