@@ -159,10 +159,20 @@ int  vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, 
 int  vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane,
                      int32_t nseq, int32_t S, int32_t S_pad, int32_t H, int32_t num, void* stream);
 
-/* fp32 small-batch linear of the DiffNet head: y[b][n] = post(W[n] . pre(x[b]) + bias[n]) (+ res[b][n]); pre/post = PReLU
- * with the given one-element slope tensors (NULL = identity).  Conv1d(k=1) on (B,C,1) (channel_attention.py:45, 58-61). */
-int  vtq_k_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope, const float* post_slope,
-                        const float* res, float* y, int32_t B, int32_t N, int32_t K, void* stream);
+/* One skinny linear stage on the MFMA pipe (CLS tail of the last layer, DiffNet head): out[R, N] = act[R, K] * W[N, K]^T + bias,
+ * operands as 16-bit planes in format `num` (VTQ_NUM_*): xa [planes][>= ceil64(R)][ldx], W [planes][ceil16(N)][K], K % 32 == 0.
+ *   epi 0 plain | 1 gelu_erf | 2 prelu(*post_slope) | 3 res + gamma * v (gamma NULL = 1) | 4 res + aux * sigmoid(v) |
+ *       5 relu for columns >= nsplit (RCAB conv with the channel-attention squeeze folded in, channel_attention.py:45, 58-61)
+ * Outputs: y fp32 [R][ldy], columns [0, ycols) (may be NULL); ya: 16-bit planes of columns [pcol0, N), stored at column
+ * c - pcol0, as prelu(value, *next_slope) when next_slope != NULL (may be NULL). */
+int  vtq_k_skinny_linear(const void* xa, int64_t xa_plane, int32_t ldx, const void* W, int64_t w_plane, int32_t R, int32_t N, int32_t K,
+                         int32_t num, int32_t epi, const float* bias, const float* post_slope, const float* gamma, const float* res,
+                         const float* aux, int32_t ldr, int32_t nsplit, float* y, int32_t ldy, int32_t ycols, void* ya, int64_t ya_plane,
+                         int32_t ldya, int32_t pcol0, const float* next_slope, void* stream);
+
+/* The DiffNet head + quality predictor alone (quality_decoder -> q_predictor, vtamiq.py:114-117, channel_attention.py:13-86) with
+ * the handle's loaded weights: d fp32 [HB][H] = diff_scale(cls_ref - cls_dist) -> q_out fp32 [HB]. */
+int  vtq_k_diffnet_head(vtq_handle h, const float* d, int32_t HB, float* q_out, void* stream);
 
 /* ---- on-device image -> patch tensor; replaces the CPU loader's transform_img (data/utils.py:76-94) and the
  * gather / position / pyramid part of get_iqa_patches (data/patch_sampling.py:529-611) for GIVEN sample coordinates ---------- */

@@ -164,27 +164,105 @@ def test_attention(fmt, nseq, S, H, packed):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("B,N,K", [(2, 768, 768), (32, 768, 768), (37, 192, 768), (64, 1, 192), (5, 768, 96), (3, 1024, 1024)])
-@pytest.mark.parametrize("mode", ["plain", "pre", "post", "res"])
-def test_small_linear(B, N, K, mode):
+def _skinny(x, W, bias, fmt, epi=0, post=None, gamma=None, res=None, aux=None, nsplit=0, want_y=True, ycols=None, planes_out=False,
+            pcol0=0, next_slope=None, Kp=None):
+    """Drive vtq_k_skinny_linear: x [R, K] fp32, W [N, K] fp32 -> (y fp32 or None, planes value fp64 or None)."""
     lib = _lib.load()
-    x, W, bias = _randn(B, K, seed=20), _randn(N, K, seed=21, scale=0.05), _randn(N, seed=22)
-    slope = torch.tensor([0.23], device=DEV)
-    res = _randn(B, N, seed=23)
-    y = torch.zeros(B, N, device=DEV)
-    _lib.check(lib.vtq_k_small_linear(x.data_ptr(), W.data_ptr(), bias.data_ptr(), slope.data_ptr() if mode == "pre" else None,
-                                      slope.data_ptr() if mode == "post" else None, res.data_ptr() if mode == "res" else None,
-                                      y.data_ptr(), B, N, K, stream()))
+    R, K = x.shape
+    N = W.shape[0]
+    Kp = Kp or K
+    Ra, Np = (R + 63) // 64 * 64, (N + 15) // 16 * 16
+    xpad = torch.zeros(Ra, Kp, device=DEV); xpad[:R, :K] = x
+    wpad = torch.zeros(Np, Kp, device=DEV); wpad[:N, :K] = W
+    xa, wp = to_planes(xpad, fmt, "a"), to_planes(wpad, fmt, "w")
+    y = torch.full((R, N), float("nan"), device=DEV) if want_y else None
+    npl = planes_of(fmt, "a")
+    ncol = N - pcol0
+    ya = torch.zeros((npl, Ra, ncol), dtype=elt_dtype(fmt), device=DEV) if planes_out else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.vtq_k_skinny_linear(xa.data_ptr(), Ra * Kp, Kp, wp.data_ptr(), Np * Kp, R, N, Kp, num_code(fmt), epi, bias.data_ptr(),
+                                       ptr(post), ptr(gamma), ptr(res), ptr(aux), N, nsplit, ptr(y), N, N if ycols is None else ycols,
+                                       ptr(ya), Ra * ncol, ncol, pcol0, ptr(next_slope), stream()))
     torch.cuda.synchronize()
-    xd = x.double()
-    if mode == "pre":
-        xd = torch.where(xd >= 0, xd, 0.23 * xd)
-    ref = xd @ W.double().t() + bias.double()
-    if mode == "post":
-        ref = torch.where(ref >= 0, ref, float(slope.double()) * ref)
-    if mode == "res":
-        ref = ref + res.double()
-    assert (y.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    return y, (planes_value(ya)[:R] if planes_out else None), planes_value(xa)[:R, :K], planes_value(wp)[:N, :K]
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("R,N,K", [(2, 768, 768), (32, 864, 768), (64, 3072, 768), (64, 768, 3072), (37, 192, 768), (130, 768, 96), (5, 1, 192)])
+def test_skinny_linear_plain(fmt, R, N, K):
+    x, W, bias = _randn(R, K, seed=20), _randn(N, K, seed=21, scale=0.05), _randn(N, seed=22)
+    y, _, xv, wv = _skinny(x, W, bias, fmt)
+    ref = xv @ wv.t() + bias.double()
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("fmt", ["fp16x3", "bf16x3", "fp16x2"])
+def test_skinny_linear_epilogues(fmt):
+    """Every epilogue form of the CLS tail and the DiffNet head, fp32 and plane outputs, K zero-padded to the k-step (hid = 48)."""
+    R, H, hid = 40, 768, 48
+    slope, nxt = torch.tensor([0.23], device=DEV), torch.tensor([0.31], device=DEV)
+    x, W, bias = _randn(R, H, seed=30), _randn(H, H, seed=31, scale=0.05), _randn(H, seed=32)
+    res, aux, gamma = _randn(R, H, seed=33), _randn(R, H, seed=34), _randn(H, seed=35)
+    prelu = lambda v, a: torch.where(v >= 0, v, a * v)
+    tolp = OUT_TOL[fmt]
+    # GELU -> planes only (tail fc1)
+    _, pv, xv, wv = _skinny(x, W, bias, fmt, epi=1, want_y=False, planes_out=True)
+    pre = xv @ wv.t() + bias.double()
+    ref = torch.nn.functional.gelu(pre)
+    assert (pv - ref).abs().max().item() < tolp * ref.abs().max().item()
+    # PReLU(post) -> planes (q_predictor.1 + .2)
+    _, pv, _, _ = _skinny(x, W, bias, fmt, epi=2, post=slope, want_y=False, planes_out=True)
+    ref = prelu(pre, 0.23)
+    assert (pv - ref).abs().max().item() < tolp * ref.abs().max().item()
+    # residual with LayerScale, in place semantics (tail out-proj / fc2) + planes with the consumer's PReLU (RG tail conv)
+    y, pv, _, _ = _skinny(x, W, bias, fmt, epi=3, gamma=gamma, res=res, planes_out=True, next_slope=nxt)
+    ref = res.double() + gamma.double() * pre
+    assert (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (pv - prelu(ref, 0.31)).abs().max().item() < tolp * ref.abs().max().item()
+    # gate: res + aux * sigmoid(v), K = hid padded to 64 (RCAB stage B)
+    t, Wu, bu = _randn(R, hid, seed=36).abs(), _randn(H, hid, seed=37, scale=0.1), _randn(H, seed=38)
+    y, pv, tv, wuv = _skinny(t, Wu, bu, fmt, epi=4, res=res, aux=aux, planes_out=True, Kp=64)
+    ref = res.double() + aux.double() * torch.sigmoid(tv @ wuv.t() + bu.double())
+    assert (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (pv - ref).abs().max().item() < tolp * ref.abs().max().item()
+    # convcat: columns < H fp32, columns >= H relu -> planes (RCAB stage A with the CA squeeze folded in)
+    Wc, bc = _randn(H + hid, H, seed=39, scale=0.05), _randn(H + hid, seed=40)
+    y, pv, xv, wcv = _skinny(x, Wc, bc, fmt, epi=5, nsplit=H, ycols=H, planes_out=True, pcol0=H)
+    full = xv @ wcv.t() + bc.double()
+    assert (y[:, :H].double() - full[:, :H]).abs().max().item() < 2e-5 * full.abs().max().item()
+    assert torch.isnan(y[:, H:]).all()                                      # fp32 columns >= ycols are not written
+    assert (pv - torch.relu(full[:, H:])).abs().max().item() < tolp * full.abs().max().item()
+
+
+@pytest.mark.parametrize("kw,HB", [(dict(), 32), (dict(ca_reduction=16, num_rgs=2, num_rcabs=3), 5), (dict(calibrate=False), 7),
+                                   (dict(vit_config=dict(variant="ViT-L16", num_keep_layers=1)), 130)])
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16"])
+def test_diffnet_head_against_oracle(kw, HB, precision):
+    """vtq_k_diffnet_head (quality_decoder -> q_predictor as skinny MFMA stages, fp16 hi/lo whatever the encoder's precision)
+    against oracle.quality_decoder / q_predictor on the same CLS differences."""
+    import ctypes as C
+    import json
+    from oracle import vtamiq_oracle as O
+    from vtamiq_amd import VTAMIQ, synth
+    kw = dict(kw)
+    kw.setdefault("vit_config", dict(variant="ViT-B16", num_keep_layers=1))
+    kw["vit_config"]["pretrained"] = False
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+    sd = synth.make_state_dict(m.spec, 61)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    H = m.spec.hidden_size
+    p = torch.zeros(1, 4, 3, 16, 16, device=DEV)
+    with torch.no_grad():
+        m((p, p), (torch.zeros(1, 4, 2, device=DEV),) * 2, ((torch.zeros(1, 4, device=DEV),) * 2 if m.spec.use_scale_embedding else (None, None)))
+    d = _randn(HB, H, seed=62, scale=0.5)
+    q = torch.zeros(HB, device=DEV)
+    _lib.check(_lib.load().vtq_k_diffnet_head(m._engine, d.data_ptr(), HB, q.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    t = O.to_torch(sd)
+    ref = O.q_predictor(t, O.quality_decoder(t, m.spec, d.cpu())).numpy()
+    err = (q.cpu().numpy() - ref)
+    assert abs(err).max() < 2e-5 * max(1.0, abs(ref).max()), (abs(err).max(), abs(ref).max())
 
 
 @pytest.mark.parametrize("tag", ["aligned", "unaligned"])

@@ -2,9 +2,10 @@
 //
 // VTAMIQ consumes token 0 of the encoder output and nothing else (modules/vtamiq/vtamiq.py:104-108), so in the LAST
 // EncoderLayer (modules/VisionTransformer/transformer.py:275-285) only the K/V projections need every row; the query,
-// the attention output, out-proj, LayerNorm_2 and the MLP are needed for the 2B CLS rows alone.  These kernels run that
-// 2B-row tail in fp32 activations against the packed 16-bit (hi[, lo]) weight planes; results are identical in exact
-// arithmetic to running the full layer and reading row 0 (SURVEY.md 8d allows the pruning; bench reports executed flops).
+// the attention output, out-proj, LayerNorm_2 and the MLP are needed for the 2B CLS rows alone.  This file holds the row
+// LayerNorm and the single-query attention of that tail; its four linear stages run on the MFMA pipe (skinny.hip).  Results are
+// identical in exact arithmetic to running the full layer and reading row 0 (SURVEY.md 8d allows the pruning; bench reports
+// executed flops).
 #include <mutex>
 
 #include "dev_common.h"
@@ -44,53 +45,6 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
         const float4 w4 = ((const float4*)w)[i * 64 + lane], b4 = ((const float4*)b)[i * 64 + lane];
         float4 y = {v[i].x * rstd * w4.x + b4.x, v[i].y * rstd * w4.y + b4.y, v[i].z * rstd * w4.z + b4.z, v[i].w * rstd * w4.w + b4.w};
         ((float4*)(ln + (int64_t)r * H))[i * 64 + lane] = y;
-    }
-}
-
-enum { ROWS_PLAIN = 0, ROWS_GELU = 1, ROWS_RESID = 2 };
-
-// y[r][n] = epi(sum_k (w_hi[n][k] + w_lo[n][k]) * x[r][k] + bias[n]);  K % 256 == 0; one wave = one n x 8 rows.
-template <typename T, int NPL, int EPI>
-__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, const T* __restrict__ W, int64_t w_plane,
-                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                          const float* __restrict__ res, float* __restrict__ y, int R, int N, int K) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const int r0 = blockIdx.y * 8;
-    const int KP = K >> 8;                        // 4-element pieces per lane
-    typedef typename Vec<T>::x4 tx4;
-    const T* wr = W + (int64_t)n * K;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int pc = 0; pc < KP; ++pc) {
-        const int idx = pc * 64 + lane;           // float4 index inside the row
-        const tx4 wh = ((const tx4*)wr)[idx];
-        float4 w4 = {(float)wh[0], (float)wh[1], (float)wh[2], (float)wh[3]};
-        if constexpr (NPL == 2) {
-            const tx4 wl = ((const tx4*)(wr + w_plane))[idx];
-            w4.x += (float)wl[0]; w4.y += (float)wl[1]; w4.z += (float)wl[2]; w4.w += (float)wl[3];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = (r0 + rr < R) ? r0 + rr : R - 1;
-            const float4 v = ((const float4*)(x + (int64_t)r * K))[idx];
-            acc[rr] += (w4.x * v.x + w4.y * v.y) + (w4.z * v.z + w4.w * v.w);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) acc[rr] += __shfl_xor(acc[rr], o, 64);
-    float mine = acc[0];
-#pragma unroll
-    for (int rr = 1; rr < 8; ++rr) mine = (lane == rr) ? acc[rr] : mine;
-    const int r = r0 + lane;
-    if (lane < 8 && r < R) {
-        float v = mine + bias[n];
-        const int64_t o = (int64_t)r * N + n;
-        if constexpr (EPI == ROWS_GELU) v = gelu_erf(v);
-        if constexpr (EPI == ROWS_RESID) v = res[o] + (gamma ? gamma[n] : 1.0f) * v;
-        y[o] = v;
     }
 }
 
@@ -177,19 +131,6 @@ hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, cons
     if (H == 768) hipLaunchKernelGGL(rows_ln_kernel<3>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
     else if (H == 1024) hipLaunchKernelGGL(rows_ln_kernel<4>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
     else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int f16_, int wplanes, const float* bias, const float* gamma,
-                              const float* res, float* y, int R, int N, int K, int epi, hipStream_t s) {
-    if (K % 256 || epi < 0 || epi > 2 || (wplanes != 1 && wplanes != 2)) return hipErrorInvalidValue;
-    const dim3 g((N + 3) / 4, (R + 7) / 8), blk(256);
-#define VTQ_RL(TT, NP, EP) hipLaunchKernelGGL((rows_linear_kernel<TT, NP, EP>), g, blk, 0, s, x, (const TT*)W, w_plane, bias, gamma, res, y, R, N, K)
-#define VTQ_RL_E(TT, NP) do { if (epi == 0) VTQ_RL(TT, NP, 0); else if (epi == 1) VTQ_RL(TT, NP, 1); else VTQ_RL(TT, NP, 2); } while (0)
-    if (!f16_) { if (wplanes == 1) VTQ_RL_E(bf16, 1); else VTQ_RL_E(bf16, 2); }
-    else { if (wplanes == 1) VTQ_RL_E(f16, 1); else VTQ_RL_E(f16, 2); }
-#undef VTQ_RL_E
-#undef VTQ_RL
     return hipGetLastError();
 }
 

@@ -54,8 +54,11 @@ struct Layer {
     int64_t pqkv, po, p1, p2;                  // plane strides
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b, *g1, *g2;
 };
-struct Rcab { float *slope, *w, *b, *wd, *bd, *wu, *bu, *wcat, *bcat; };   // wcat/bcat: [Wc ; Wd Wc], folded at load time
-struct Rg { std::vector<Rcab> rcabs; float *w, *b; };
+// One linear stage of the DiffNet head as the skinny-MFMA kernel reads it: fp16 hi/lo planes [2][ceil16(N)][Kp] (Kp = K padded
+// to the 32-deep k-step with zeros) + fp32 bias.  The head always runs the 3-term fp16 form, whatever the encoder's precision.
+struct HeadLin { void* wp = nullptr; int64_t plane = 0; int N = 0, K = 0, Kp = 0; const float* b = nullptr; };
+struct Rcab { float *slope, *w, *b, *wd, *bd, *wu, *bu, *wcat, *bcat; HeadLin cat, up; };   // wcat/bcat: [Wc ; Wd Wc], folded at load time
+struct Rg { std::vector<Rcab> rcabs; float *w, *b; HeadLin tail; };
 
 }  // namespace
 
@@ -75,6 +78,7 @@ struct vtq_engine {
     float* diff_gamma = nullptr;
     std::vector<Rg> rgs;
     float *qdw = nullptr, *qdb = nullptr, *p1w = nullptr, *p1b = nullptr, *p2a = nullptr, *p4w = nullptr, *p4b = nullptr;
+    HeadLin qd, p1, p4;
     // workspace
     int capB = 0, capN = 0;
     int64_t rows_alloc = 0;
@@ -84,7 +88,13 @@ struct vtq_engine {
     int *pidx = nullptr, *sidx = nullptr, *row_map = nullptr;
     float* hb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* hhid = nullptr;
-    float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr, *h1cls = nullptr;   // CLS-only last layer
+    int r_alloc = 0;                     // rows of the skinny-stage plane buffers (multiple of 64)
+    void *hp[2] = {nullptr, nullptr}, *ht = nullptr, *hq = nullptr;   // head planes (fp16 hi/lo): [r_alloc][H] x2, [r_alloc][hidp], [r_alloc][H/4]
+    int64_t hp_plane = 0, ht_plane = 0, hq_plane = 0;
+    int hidp = 0;
+    void *tl = nullptr, *th = nullptr;   // CLS-tail planes (encoder format): [r_alloc][H], [r_alloc][M]
+    int64_t tl_plane = 0, th_plane = 0;
+    float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr;   // CLS-only last layer (fp32 rows)
     bool cls_prune = true;
     int* err_flag = nullptr;             // device word: bit 0 = a position outside [0, 1) was clamped (vtq_input_errors)
     std::vector<void*> ws_allocs;
@@ -190,7 +200,41 @@ int build(vtq_engine* e) {
         add_f32(e, "q_predictor.2.weight", &e->p2a, 1) || add_f32(e, "q_predictor.4.weight", &e->p4w, H / 4) ||
         add_f32(e, "q_predictor.4.bias", &e->p4b, 1))
         return 1;
+    // fp16 hi/lo planes of every head matrix (filled by pack_head after each weight load)
+    auto head_lin = [&](HeadLin& L, int N, int K, const float* bias) {
+        L.N = N; L.K = K; L.Kp = (int)round_up(K, 32); L.b = bias;
+        L.plane = round_up(N, 16) * L.Kp;
+        if (dev_alloc(e, &L.wp, (size_t)L.plane * 2 * 2)) return 1;
+        return hipMemset(L.wp, 0, (size_t)L.plane * 2 * 2) == hipSuccess ? 0 : fail("hipMemset failed");
+    };
+    if (c.calibrate) {
+        for (auto& R : e->rgs) {
+            for (auto& r : R.rcabs)
+                if (head_lin(r.cat, (int)H + c.ca_hidden, (int)H, r.bcat) || head_lin(r.up, (int)H, c.ca_hidden, r.bu)) return 1;
+            if (head_lin(R.tail, (int)H, (int)H, R.b)) return 1;
+        }
+        if (head_lin(e->qd, (int)H, (int)H, e->qdb)) return 1;
+    }
+    if (head_lin(e->p1, (int)H / 4, (int)H, e->p1b) || head_lin(e->p4, 1, (int)H / 4, e->p4b)) return 1;
+    e->hidp = (int)round_up(c.ca_hidden > 0 ? c.ca_hidden : 32, 32);
     return 0;
+}
+
+// fp32 matrices of the head -> the fp16 planes the skinny kernel streams (after the CA fold); enqueued on s
+int pack_head(vtq_engine* e, hipStream_t s) {
+    auto pack = [&](const HeadLin& L, const float* W) {
+        HIP_TRY(launch_rows_to_planes(W, L.K, nullptr, L.wp, L.plane, L.Kp, L.N, L.K, 1, 2, s));
+        return 0;
+    };
+    for (auto& R : e->rgs) {
+        for (auto& r : R.rcabs) {
+            HIP_TRY(launch_fold_ca(r.w, r.b, r.wd, r.bd, r.wcat, r.bcat, e->H, e->cfg.ca_hidden, s));
+            if (pack(r.cat, r.wcat) || pack(r.up, r.wu)) return 1;
+        }
+        if (pack(R.tail, R.w)) return 1;
+    }
+    if (e->cfg.calibrate && pack(e->qd, e->qdw)) return 1;
+    return pack(e->p1, e->p1w) || pack(e->p4, e->p4w);
 }
 
 struct Geometry {
@@ -231,7 +275,10 @@ size_t workspace_bytes(const vtq_engine* e, int B, int N) {
     b += (size_t)rows * Wmax * 2 * e->apl;                // qkv | mlp hidden | packed patches planes
     b += (size_t)P_pad * 4 * 3;                           // pos/scale indices, row map
     b += (size_t)2 * B * H * 4 * 6;                       // head ping-pong buffers (pairwise: 2 scores per item)
-    b += (size_t)2 * B * (4 * H + e->Mdim) * 4;           // CLS-only last-layer rows
+    b += (size_t)2 * B * 4 * H * 4;                       // CLS-only last-layer rows (fp32)
+    const size_t ra = (size_t)round_up((int64_t)2 * B, 64);
+    b += ra * (2 * H + e->hidp + H / 4) * 2 * 2;          // head planes (fp16 hi/lo)
+    b += ra * (H + e->Mdim) * 2 * e->apl;                 // CLS-tail planes
     return b;
 }
 
@@ -257,9 +304,25 @@ int reserve(vtq_engine* e, int B, int N) {
     for (int i = 0; i < 5; ++i)
         if (dev_alloc(e, (void**)&e->hb[i], (size_t)2 * nB * H * 4, true)) return 1;
     if (dev_alloc(e, (void**)&e->xcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->lncls, (size_t)2 * nB * H * 4, true) ||
-        dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->acls, (size_t)2 * nB * H * 4, true) ||
-        dev_alloc(e, (void**)&e->h1cls, (size_t)2 * nB * e->Mdim * 4, true))
+        dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->acls, (size_t)2 * nB * H * 4, true))
         return 1;
+    {
+        const int64_t ra = round_up((int64_t)2 * nB, 64);
+        e->r_alloc = (int)ra;
+        e->hp_plane = ra * H; e->ht_plane = ra * e->hidp; e->hq_plane = ra * (H / 4);
+        e->tl_plane = ra * H; e->th_plane = ra * e->Mdim;
+        if (dev_alloc(e, &e->hp[0], (size_t)e->hp_plane * 4, true) || dev_alloc(e, &e->hp[1], (size_t)e->hp_plane * 4, true) ||
+            dev_alloc(e, &e->ht, (size_t)e->ht_plane * 4, true) || dev_alloc(e, &e->hq, (size_t)e->hq_plane * 4, true) ||
+            dev_alloc(e, &e->tl, (size_t)e->tl_plane * 2 * e->apl, true) || dev_alloc(e, &e->th, (size_t)e->th_plane * 2 * e->apl, true))
+            return 1;
+        // rows >= R and the K-padding columns are read by the MFMA stages: zero once, never written
+        HIP_TRY(hipMemset(e->hp[0], 0, (size_t)e->hp_plane * 4));
+        HIP_TRY(hipMemset(e->hp[1], 0, (size_t)e->hp_plane * 4));
+        HIP_TRY(hipMemset(e->ht, 0, (size_t)e->ht_plane * 4));
+        HIP_TRY(hipMemset(e->hq, 0, (size_t)e->hq_plane * 4));
+        HIP_TRY(hipMemset(e->tl, 0, (size_t)e->tl_plane * 2 * e->apl));
+        HIP_TRY(hipMemset(e->th, 0, (size_t)e->th_plane * 2 * e->apl));
+    }
     // finite contents everywhere: padded rows are computed on (never consumed) and must not breed NaNs
     HIP_TRY(hipMemset(e->x, 0, (size_t)g.rows_alloc * H * 4));
     HIP_TRY(hipMemset(e->lnbuf, 0, (size_t)e->ln_plane * 2 * e->apl));
@@ -289,13 +352,13 @@ struct Prof {
 // All encoder layers for the g.nseq sequences, enqueued on s.
 int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     const vtq_config& c = e->cfg;
-    const int H = e->H, Md = e->Mdim, T = e->T, L = c.num_layers, f16 = e->f16, apl = e->apl, wpl = e->wpl;
+    const int H = e->H, Md = e->Mdim, T = e->T, L = c.num_layers, f16 = e->f16, apl = e->apl;
     const Num lin = e->lin;
     const int M = (int)g.M_pad;
     float* x = e->x;
     char* lnb = (char*)e->lnbuf;
     char* big = (char*)e->big;                               // QKV (ld 3H) and the MLP hidden (ld M) alias: never live together
-    float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls, *acls = e->acls, *h1cls = e->h1cls;
+    float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls, *acls = e->acls;
     const int64_t trace_stride = (int64_t)g.nseq * T * H;
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
@@ -314,17 +377,40 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             }
             {
                 Prof p(e, s, VTQ_K_HEAD);
+                // skinny MFMA stages on the R CLS rows (skinny.hip); activations between them as planes in the encoder's format
+                auto stage = [&](const void* xa, int64_t xpl, int ldx, const void* W, int64_t wpl_, int N, int K, const float* bias) {
+                    SkinnyArgs a{};
+                    a.xa = xa; a.xa_plane = xpl; a.ldx = ldx; a.W = W; a.w_plane = wpl_; a.R = R; a.N = N; a.K = K; a.bias = bias;
+                    a.ya_planes = apl;
+                    return a;
+                };
                 HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, s));
-                HIP_TRY(launch_rows_linear(lncls, Ly.wqkv, Ly.pqkv, f16, wpl, Ly.bqkv, nullptr, nullptr, qcls, R, H, H, 0, s));
+                HIP_TRY(launch_rows_to_planes(lncls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                {   // query projection: rows 0 .. H-1 of the packed QKV weight
+                    SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wqkv, Ly.pqkv, H, H, Ly.bqkv);
+                    a.epi = SK_PLAIN; a.y = qcls; a.ldy = H; a.ycols = H;
+                    HIP_TRY(launch_skinny(a, lin, s));
+                }
                 HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, f16, apl, s));
+                HIP_TRY(launch_rows_to_planes(acls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                {   // out-proj + LayerScale + residual, in place on the CLS rows
+                    SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wo, Ly.po, H, H, Ly.bo);
+                    a.epi = SK_RESID; a.gamma = Ly.g1; a.res = xcls; a.ldr = H; a.y = xcls; a.ldy = H; a.ycols = H;
+                    HIP_TRY(launch_skinny(a, lin, s));
+                }
+                HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s));
+                HIP_TRY(launch_rows_to_planes(lncls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                {   // fc1 + GELU -> planes
+                    SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.w1, Ly.p1, Md, H, Ly.b1);
+                    a.epi = SK_GELU; a.ya = e->th; a.ya_plane = e->th_plane; a.ldya = Md;
+                    HIP_TRY(launch_skinny(a, lin, s));
+                }
+                {   // fc2 + LayerScale + residual
+                    SkinnyArgs a = stage(e->th, e->th_plane, Md, Ly.w2, Ly.p2, H, Md, Ly.b2);
+                    a.epi = SK_RESID; a.gamma = Ly.g2; a.res = xcls; a.ldr = H; a.y = xcls; a.ldy = H; a.ycols = H;
+                    HIP_TRY(launch_skinny(a, lin, s));
+                }
             }
-            {
-                Prof p(e, s, VTQ_K_HEAD);
-                HIP_TRY(launch_rows_linear(acls, Ly.wo, Ly.po, f16, wpl, Ly.bo, Ly.g1, xcls, xcls, R, H, H, 2, s));
-            }
-            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s)); }
-            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(lncls, Ly.w1, Ly.p1, f16, wpl, Ly.b1, nullptr, nullptr, h1cls, R, Md, H, 1, s)); }
-            { Prof p(e, s, VTQ_K_HEAD); HIP_TRY(launch_rows_linear(h1cls, Ly.w2, Ly.p2, f16, wpl, Ly.b2, Ly.g2, xcls, xcls, R, H, Md, 2, s)); }
             break;
         }
         { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
@@ -359,6 +445,83 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
         }
         if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride, g.nseq, g.sm, T, H, s));
+    }
+    return 0;
+}
+
+// DiffNet head + quality predictor on d[HB][H] (the CLS difference after diff_scale; vtamiq.py:111-117,
+// channel_attention.py:13-86) as a chain of skinny MFMA stages (skinny.hip), fp16 hi/lo operands, fp32 everywhere else.
+//   RCAB (channel_attention.py:41-50, 77-86) = two stages with the CA squeeze folded into the conv (launch_fold_ca):
+//     [c | t] = [Wc ; Wd Wc] prelu(r) + bcat, t = relu(.)        y = r + c * sigmoid(Wu t + bu)
+//   Every stage writes the planes its consumer reads, already passed through the consumer's PReLU.
+int run_head(vtq_engine* e, const float* d, int HB, float* q_out, hipStream_t s) {
+    const vtq_config& c = e->cfg;
+    const int H = e->H;
+    const Num h3{1, 3};
+    if (HB > e->r_alloc) return fail("run_head: %d rows exceed the reserved %d", HB, e->r_alloc);
+    auto stage = [&](const void* xa, int64_t xpl, int ldx, const HeadLin& L) {
+        SkinnyArgs a{};
+        a.xa = xa; a.xa_plane = xpl; a.ldx = ldx; a.W = L.wp; a.w_plane = L.plane; a.R = HB; a.N = L.N; a.K = L.Kp; a.bias = L.b;
+        a.ya_planes = 2;
+        return a;
+    };
+    void *pin = e->hp[0], *pout = e->hp[1];
+    const float* first_slope = (c.calibrate && !e->rgs.empty()) ? e->rgs[0].rcabs[0].slope : nullptr;
+    HIP_TRY(launch_rows_to_planes(d, H, first_slope, pin, e->hp_plane, H, HB, H, 1, 2, s));
+    if (c.calibrate) {
+        const float* xr = d;                 // residual-group input (fp32)
+        float* xr_buf[2] = {e->hb[1], e->hb[0]};      // d lives in hb[0]: the first RG writes hb[1]
+        float *y0 = e->hb[2], *y1 = e->hb[3], *cb = e->hb[4];
+        const size_t ng = e->rgs.size();
+        for (size_t gi = 0; gi < ng; ++gi) {
+            Rg& R = e->rgs[gi];
+            const float* y = xr;
+            float* yo = y0;
+            const size_t nr = R.rcabs.size();
+            for (size_t k = 0; k < nr; ++k) {
+                Rcab& r = R.rcabs[k];
+                {
+                    SkinnyArgs a = stage(pin, e->hp_plane, H, r.cat);
+                    a.epi = SK_CONVCAT; a.nsplit = H; a.y = cb; a.ldy = H; a.ycols = H;
+                    a.ya = e->ht; a.ya_plane = e->ht_plane; a.ldya = e->hidp; a.pcol0 = H;
+                    HIP_TRY(launch_skinny(a, h3, s));
+                }
+                {
+                    SkinnyArgs a = stage(e->ht, e->ht_plane, e->hidp, r.up);
+                    a.epi = SK_GATE; a.res = y; a.aux = cb; a.ldr = H; a.y = yo; a.ldy = H; a.ycols = H;
+                    a.ya = pout; a.ya_plane = e->hp_plane; a.ldya = H;
+                    a.next_slope = (k + 1 < nr) ? R.rcabs[k + 1].slope : nullptr;      // the RG tail conv takes y itself
+                    HIP_TRY(launch_skinny(a, h3, s));
+                }
+                y = yo;
+                yo = (yo == y0) ? y1 : y0;
+                std::swap(pin, pout);
+            }
+            {   // x + Conv1d(body(x))   (channel_attention.py:28-29; DropPath is identity in eval)
+                float* xn = xr_buf[gi & 1];
+                SkinnyArgs a = stage(pin, e->hp_plane, H, R.tail);
+                a.epi = SK_RESID; a.res = xr; a.ldr = H; a.y = xn; a.ldy = H; a.ycols = H;
+                a.ya = pout; a.ya_plane = e->hp_plane; a.ldya = H;
+                a.next_slope = (gi + 1 < ng) ? e->rgs[gi + 1].rcabs[0].slope : nullptr;
+                HIP_TRY(launch_skinny(a, h3, s));
+                xr = xn;
+                std::swap(pin, pout);
+            }
+        }
+        {   // final Conv1d of the decoder (vtamiq.py:22): only the planes for the predictor are needed
+            SkinnyArgs a = stage(pin, e->hp_plane, H, e->qd);
+            a.epi = SK_PLAIN; a.ya = pout; a.ya_plane = e->hp_plane; a.ldya = H;
+            HIP_TRY(launch_skinny(a, h3, s));
+            std::swap(pin, pout);
+        }
+    }
+    {   // q_predictor (vtamiq.py:71-77): Linear(H, H/4) -> PReLU -> Linear(H/4, 1)
+        SkinnyArgs a = stage(pin, e->hp_plane, H, e->p1);
+        a.epi = SK_PRELU; a.post_slope = e->p2a; a.ya = e->hq; a.ya_plane = e->hq_plane; a.ldya = H / 4;
+        HIP_TRY(launch_skinny(a, h3, s));
+        SkinnyArgs b = stage(e->hq, e->hq_plane, H / 4, e->p4);
+        b.epi = SK_PLAIN; b.y = q_out; b.ldy = 1; b.ycols = 1;
+        HIP_TRY(launch_skinny(b, h3, s));
     }
     return 0;
 }
@@ -432,9 +595,7 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
     }
-    for (auto& R : e->rgs)
-        for (auto& r : R.rcabs)
-            HIP_TRY(launch_fold_ca(r.w, r.b, r.wd, r.bd, r.wcat, r.bcat, e->H, e->cfg.ca_hidden, s));
+    if (pack_head(e, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
@@ -528,26 +689,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         float* d = e->hb[0];
         if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, s));
         else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, s));
-        if (c.calibrate) {
-            float* xr = e->hb[0];       // residual-group input
-            float* xr_next = e->hb[1];
-            float *y0 = e->hb[2], *y1 = e->hb[3], *cb = e->hb[4];
-            for (auto& R : e->rgs) {
-                const float* y = xr;
-                float* yo = y0;
-                for (auto& r : R.rcabs) {
-                    HIP_TRY(launch_rcab(y, r.slope, r.wcat, r.bcat, r.wu, r.bu, cb, e->hhid, yo, HB, H, c.ca_hidden, s));
-                    y = yo;
-                    yo = (yo == y0) ? y1 : y0;
-                }
-                HIP_TRY(launch_small_linear(y, R.w, R.b, nullptr, nullptr, xr, xr_next, HB, H, H, s));
-                float* t = xr; xr = xr_next; xr_next = t;
-            }
-            HIP_TRY(launch_small_linear(xr, e->qdw, e->qdb, nullptr, nullptr, nullptr, xr_next, HB, H, H, s));
-            d = xr_next;
-        }
-        HIP_TRY(launch_small_linear(d, e->p1w, e->p1b, nullptr, e->p2a, nullptr, e->hhid, HB, H / 4, H, s));
-        HIP_TRY(launch_small_linear(e->hhid, e->p4w, e->p4b, nullptr, nullptr, nullptr, q_out, HB, 1, H / 4, s));
+        if (run_head(e, d, HB, q_out, s)) return 1;
     }
     return 0;
 }
@@ -619,10 +761,28 @@ int vtq_k_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, 
     return 0;
 }
 
-int vtq_k_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope, const float* post_slope,
-                       const float* res, float* y, int32_t B, int32_t N, int32_t K, void* stream) {
-    HIP_TRY(launch_small_linear(x, W, bias, pre_slope, post_slope, res, y, B, N, K, (hipStream_t)stream));
+int vtq_k_skinny_linear(const void* xa, int64_t xa_plane, int32_t ldx, const void* W, int64_t w_plane, int32_t R, int32_t N, int32_t K,
+                        int32_t num, int32_t epi, const float* bias, const float* post_slope, const float* gamma, const float* res,
+                        const float* aux, int32_t ldr, int32_t nsplit, float* y, int32_t ldy, int32_t ycols, void* ya, int64_t ya_plane,
+                        int32_t ldya, int32_t pcol0, const float* next_slope, void* stream) {
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm)) return fail("vtq_k_skinny_linear: operand format code %d", num);
+    if (epi < SK_PLAIN || epi > SK_CONVCAT) return fail("vtq_k_skinny_linear: epilogue %d", epi);
+    SkinnyArgs a{};
+    a.xa = xa; a.xa_plane = xa_plane; a.ldx = ldx; a.W = W; a.w_plane = w_plane; a.R = R; a.N = N; a.K = K; a.bias = bias; a.epi = epi;
+    a.post_slope = post_slope; a.gamma = gamma; a.res = res; a.aux = aux; a.ldr = ldr; a.nsplit = nsplit;
+    a.y = y; a.ldy = ldy; a.ycols = ycols; a.ya = ya; a.ya_plane = ya_plane; a.ldya = ldya; a.ya_planes = nm.apl(); a.pcol0 = pcol0;
+    a.next_slope = next_slope;
+    HIP_TRY(launch_skinny(a, nm, (hipStream_t)stream));
     return 0;
+}
+
+int vtq_k_diffnet_head(vtq_handle e, const float* d, int32_t HB, float* q_out, void* stream) {
+    if (!e || !d || !q_out || HB < 1) return fail("vtq_k_diffnet_head: bad argument");
+    for (auto& kv : e->slots)
+        if (!kv.second.loaded) return fail("vtq_k_diffnet_head: weight '%s' was never loaded", kv.first.c_str());
+    if (reserve(e, (HB + 1) / 2, 1)) return 1;
+    return run_head(e, d, HB, q_out, (hipStream_t)stream);
 }
 
 int vtq_k_repeat_mean(const float* q, double* out, int32_t R, int32_t N, void* stream) {

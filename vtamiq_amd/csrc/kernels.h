@@ -86,22 +86,37 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
                              SeqMap sm, int H, hipStream_t s);
 
-// y[b][n] = post( sum_k W[n][k] * pre(x[b][k]) + bias[n] ) (+ res[b][n]);  pre/post: optional PReLU(slope ptr)
-hipError_t launch_small_linear(const float* x, const float* W, const float* bias, const float* pre_slope,
-                               const float* post_slope, const float* res, float* y, int B, int N, int K, hipStream_t s);
-
-// RCAB in two launches with folded weights [Wc ; Wd Wc] (launch_fold_ca, once per weight load): c, t scratch; out = r + c * sigmoid(Wu t + bu)
-hipError_t launch_rcab(const float* r, const float* slope, const float* Wcat, const float* bcat, const float* Wu, const float* bu,
-                       float* c, float* t, float* out, int B, int H, int hid, hipStream_t s);
+// one-time RCAB weight fold [Wc ; Wd Wc], bcat = [bc ; Wd bc + bd] (head.hip)
 hipError_t launch_fold_ca(const float* Wc, const float* bc, const float* Wd, const float* bd, float* Wcat, float* bcat, int H, int hid,
                           hipStream_t s);
+
+// ---- skinny linear stages on MFMA (skinny.hip): CLS tail of the last layer and the DiffNet head --------------------------
+enum { SK_PLAIN = 0, SK_GELU = 1, SK_PRELU = 2, SK_RESID = 3, SK_GATE = 4, SK_CONVCAT = 5 };
+struct SkinnyArgs {
+    const void* xa; int64_t xa_plane; int ldx;    // activation planes [apl][>= ceil64(R)][ldx] (16-bit), ldx >= K, ldx % 8 == 0
+    const void* W; int64_t w_plane;               // weight planes [wpl][ceil16(N)][K]
+    int R, N, K;                                  // valid rows / outputs; K % 32 == 0 (zero-padded)
+    const float* bias;                            // [N]
+    int epi;                                      // SK_*: v = acc + bias, then
+                                                  //   GELU gelu(v) | PRELU prelu(v, *post_slope) | RESID res + gamma * v (gamma NULL = 1)
+                                                  //   GATE res + aux * sigmoid(v) | CONVCAT relu(v) for columns >= nsplit
+    const float* post_slope;
+    const float* gamma;
+    const float* res; const float* aux; int ldr;  // fp32 [R][ldr]
+    int nsplit;
+    float* y; int ldy; int ycols;                 // fp32 output (or NULL): columns [0, ycols)
+    void* ya; int64_t ya_plane; int ldya;         // 16-bit plane output (or NULL): columns [pcol0, N) stored at column c - pcol0,
+    int ya_planes; int pcol0;                     //   as prelu(value, *next_slope) when next_slope != NULL (the consumer's pre-activation)
+    const float* next_slope;
+};
+hipError_t launch_skinny(const SkinnyArgs& a, Num num, hipStream_t s);
+// fp32 rows [R][ldx] -> 16-bit planes [R][ldo] (K columns), PReLU(*slope) first when slope != NULL
+hipError_t launch_rows_to_planes(const float* x, int ldx, const float* slope, void* out, int64_t plane, int ldo, int R, int K, int f16,
+                                 int planes, hipStream_t s);
 
 // ---- CLS-only tail of the last encoder layer (cls_tail.hip) -----------------------------------------------------------
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
                           hipStream_t s);
-// y[r][n] = epi(W[n] . x[r] + bias[n]) with W as 16-bit planes (f16, wplanes); epi 0 plain, 1 GELU, 2 res[r][n] + gamma[n] * v
-hipError_t launch_rows_linear(const float* x, const void* W, int64_t w_plane, int f16, int wplanes, const float* bias, const float* gamma,
-                              const float* res, float* y, int R, int N, int K, int epi, hipStream_t s);
 // K, V rows of the packed qkv planes (f16, planes); any S (the score buffer is dynamic LDS)
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
                                 int f16, int planes, hipStream_t s);
