@@ -18,7 +18,7 @@ namespace {
 template <int V4>
 __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ src, int64_t stride, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ ln, float* __restrict__ copy,
-                                                      int rows) {
+                                                      int rows, PlaneOut po) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -45,50 +45,65 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
         const float4 w4 = ((const float4*)w)[i * 64 + lane], b4 = ((const float4*)b)[i * 64 + lane];
         float4 y = {v[i].x * rstd * w4.x + b4.x, v[i].y * rstd * w4.y + b4.y, v[i].z * rstd * w4.z + b4.z, v[i].w * rstd * w4.w + b4.w};
         ((float4*)(ln + (int64_t)r * H))[i * 64 + lane] = y;
+        plane_store4(po, r, (i * 64 + lane) * 4, y.x, y.y, y.z, y.w);
     }
 }
 
-// attention of the single CLS query of each (sequence, head) over the S keys of the sequence; K, V from the packed bf16 planes.
-// One 4-wave workgroup per (sequence, head): thread t scores keys t, t+256, ...; wave w accumulates the keys = w (mod 4)
-// of the PV sum, four keys in flight per iteration; partial maxima / sums / outputs meet in LDS.
+// attention of the single CLS query of each (sequence, head) over the S keys of the sequence; K, V from the packed 16-bit planes.
+// One 4-wave workgroup per (sequence, head): thread t scores keys t, t+256, ... (one 128-byte K row per plane per key); for the
+// PV sum thread t owns 8 output dims (t & 7) of key group t >> 3 and walks keys kg, kg+32, ... with 16-byte V loads, four keys
+// in flight; partial maxima / sums / outputs meet in LDS.
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ q, const T* __restrict__ qkv, int64_t plane,
-                                                            float* __restrict__ out, int S, int S_pad, int H) {
+                                                            float* __restrict__ out, int S, int S_pad, int H, PlaneOut po) {
     typedef typename Vec<T>::x8 tx8;
-    extern __shared__ __attribute__((aligned(16))) float cls_smem[];     // [8] red | [4][64] part | [S] scores
+    extern __shared__ __attribute__((aligned(16))) float cls_smem[];     // [8] red | [32][64] part | [S] scores
     float* red = cls_smem;
     float (*part)[64] = (float (*)[64])(cls_smem + 8);
-    float* ps = cls_smem + 8 + 256;
+    float* ps = cls_smem + 8 + 32 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, seq = blockIdx.y;
     const int ld = 3 * H;
     const T* kb = qkv + ((int64_t)seq * S_pad) * ld + H + head * 64;
     const T* vb = kb + H;
-    float qv[64];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float4 t = ((const float4*)(q + (int64_t)seq * H + head * 64))[i];
-        qv[4 * i] = t.x; qv[4 * i + 1] = t.y; qv[4 * i + 2] = t.z; qv[4 * i + 3] = t.w;
+    // scores: 8 threads per key, each one 16-byte chunk of the key row, so a wave instruction reads 8 whole 128-byte rows (one
+    // thread per key made every load touch 64 different lines and thrashed the L1: 127 us at 64 x 501 x 12 heads)
+    const int kg = tid >> 3, dc = (tid & 7) * 8;
+    float qv[8];
+    {
+        const float4 t0 = *(const float4*)(q + (int64_t)seq * H + head * 64 + dc), t1 = *(const float4*)(q + (int64_t)seq * H + head * 64 + dc + 4);
+        qv[0] = t0.x; qv[1] = t0.y; qv[2] = t0.z; qv[3] = t0.w; qv[4] = t1.x; qv[5] = t1.y; qv[6] = t1.z; qv[7] = t1.w;
     }
     float mx = -INFINITY;
-    for (int key = tid; key < S; key += 256) {
-        const T* kr = kb + (int64_t)key * ld;
-        float s = 0.f;
+    auto score_key = [&](int key) {
+        const T* kr = kb + (int64_t)key * ld + dc;
+        const tx8 kh = *(const tx8*)kr;
+        tx8 kl;
+        if constexpr (NPL == 2) kl = *(const tx8*)(kr + plane);
+        float sc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const tx8 kh = ((const tx8*)kr)[c];
-            tx8 kl;
-            if constexpr (NPL == 2) kl = ((const tx8*)(kr + plane))[c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float kv = (float)kh[e];
-                if constexpr (NPL == 2) kv += (float)kl[e];
-                s += qv[c * 8 + e] * kv;
-            }
+        for (int e = 0; e < 8; ++e) {
+            float kv = (float)kh[e];
+            if constexpr (NPL == 2) kv += (float)kl[e];
+            sc += qv[e] * kv;
         }
-        s *= 0.125f;
-        ps[key] = s;
-        mx = fmaxf(mx, s);
+        return sc;
+    };
+    auto finish = [&](int key, float sc) {
+        sc += __shfl_xor(sc, 1, 64);
+        sc += __shfl_xor(sc, 2, 64);
+        sc += __shfl_xor(sc, 4, 64);
+        sc *= 0.125f;
+        if ((tid & 7) == 0) ps[key] = sc;
+        mx = fmaxf(mx, sc);
+    };
+    {
+        int key = kg;
+        for (; key + 96 < S; key += 128) {
+            const float s0 = score_key(key), s1 = score_key(key + 32), s2 = score_key(key + 64), s3 = score_key(key + 96);
+            finish(key, s0); finish(key + 32, s1); finish(key + 64, s2); finish(key + 96, s3);
+        }
+        for (; key < S; key += 32) finish(key, score_key(key));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -105,41 +120,58 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
-    // out[d = lane] = sum_key p[key] * V[key][d]; wave w takes keys w, w+4, ...
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    auto vat = [&](int key) {
-        float vv = (float)vb[(int64_t)key * ld + lane];
-        if constexpr (NPL == 2) vv += (float)vb[(int64_t)key * ld + plane + lane];
-        return vv;
+    // out[d] = sum_key p[key] * V[key][d]
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto acc_key = [&](int key) {
+        const T* vr = vb + (int64_t)key * ld + dc;
+        const tx8 vh = *(const tx8*)vr;
+        tx8 vl;
+        if constexpr (NPL == 2) vl = *(const tx8*)(vr + plane);
+        const float pk = ps[key];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float vv = (float)vh[e];
+            if constexpr (NPL == 2) vv += (float)vl[e];
+            o[e] += pk * vv;
+        }
     };
-    int key = wave;
-    for (; key + 12 < S; key += 16) {
-        const float v0 = vat(key), v1 = vat(key + 4), v2 = vat(key + 8), v3 = vat(key + 12);
-        o0 += ps[key] * v0; o1 += ps[key + 4] * v1; o2 += ps[key + 8] * v2; o3 += ps[key + 12] * v3;
-    }
-    for (; key < S; key += 4) o0 += ps[key] * vat(key);
-    part[wave][lane] = (o0 + o1) + (o2 + o3);
+    int key = kg;
+    for (; key + 96 < S; key += 128) { acc_key(key); acc_key(key + 32); acc_key(key + 64); acc_key(key + 96); }
+    for (; key < S; key += 32) acc_key(key);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[kg][dc + e] = o[e];
     __syncthreads();
-    if (wave == 0) out[(int64_t)seq * H + head * 64 + lane] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / sum;
+    if (tid < 16) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const float4 pv = *(const float4*)&part[g][4 * tid];
+            t[0] += pv.x; t[1] += pv.y; t[2] += pv.z; t[3] += pv.w;
+        }
+        const float inv = 1.0f / sum;
+        const int col = head * 64 + 4 * tid;
+        if (out) *(float4*)(out + (int64_t)seq * H + col) = float4{t[0] * inv, t[1] * inv, t[2] * inv, t[3] * inv};
+        plane_store4(po, seq, col, t[0] * inv, t[1] * inv, t[2] * inv, t[3] * inv);
+    }
 }
 
 }  // namespace
 
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
-                          hipStream_t s) {
+                          PlaneOut po, hipStream_t s) {
     const dim3 g((rows + 3) / 4), blk(256);
-    if (H == 768) hipLaunchKernelGGL(rows_ln_kernel<3>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
-    else if (H == 1024) hipLaunchKernelGGL(rows_ln_kernel<4>, g, blk, 0, s, src, stride, w, b, ln, copy, rows);
+    if (H == 768) hipLaunchKernelGGL(rows_ln_kernel<3>, g, blk, 0, s, src, stride, w, b, ln, copy, rows, po);
+    else if (H == 1024) hipLaunchKernelGGL(rows_ln_kernel<4>, g, blk, 0, s, src, stride, w, b, ln, copy, rows, po);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 namespace {
 constexpr int kClsLdsMax = 160 * 1024 - 4096;                 // leave room for the runtime's own LDS use
-constexpr int kClsFixed = (8 + 256) * 4;
+constexpr int kClsFixed = (8 + 32 * 64) * 4;
 template <typename T, int NPL>
 hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                  hipStream_t s) {
+                                  PlaneOut po, hipStream_t s) {
     const int lds = kClsFixed + ((S + 3) & ~3) * 4;
     if (lds > 48 * 1024) {                                    // beyond the default limit: raise it once per device
         static std::mutex mu;
@@ -155,7 +187,7 @@ hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane
             configured[dev] = true;
         }
     }
-    hipLaunchKernelGGL((cls_attention_kernel<T, NPL>), dim3(H / 64, nseq), dim3(256), lds, s, q, (const T*)qkv, plane, out, S, S_pad, H);
+    hipLaunchKernelGGL((cls_attention_kernel<T, NPL>), dim3(H / 64, nseq), dim3(256), lds, s, q, (const T*)qkv, plane, out, S, S_pad, H, po);
     return hipGetLastError();
 }
 }  // namespace
@@ -163,12 +195,12 @@ hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane
 int cls_attention_max_seq() { return (kClsLdsMax - kClsFixed) / 4; }
 
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int f16_, int planes, hipStream_t s) {
+                                int f16_, int planes, PlaneOut po, hipStream_t s) {
     if (S < 1 || S > cls_attention_max_seq() || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
-    if (!f16_) return planes == 1 ? launch_cls_attention_t<bf16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, s)
-                                  : launch_cls_attention_t<bf16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, s);
-    return planes == 1 ? launch_cls_attention_t<f16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, s)
-                       : launch_cls_attention_t<f16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, s);
+    if (!f16_) return planes == 1 ? launch_cls_attention_t<bf16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s)
+                                  : launch_cls_attention_t<bf16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s);
+    return planes == 1 ? launch_cls_attention_t<f16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s)
+                       : launch_cls_attention_t<f16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s);
 }
 
 }  // namespace vtq

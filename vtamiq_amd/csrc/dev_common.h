@@ -1,5 +1,6 @@
 // Device-side helpers shared by the gfx950 kernels.  CDNA4 only: wave = 64 lanes, MFMA bf16 / f16, LDS-DMA.
 #pragma once
+#define VTQ_DEV_COMMON 1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -91,3 +92,4 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 #define VTQ_WAVE 64
+

@@ -94,7 +94,7 @@ struct vtq_engine {
     int hidp = 0;
     void *tl = nullptr, *th = nullptr;   // CLS-tail planes (encoder format): [r_alloc][H], [r_alloc][M]
     int64_t tl_plane = 0, th_plane = 0;
-    float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr, *acls = nullptr;   // CLS-only last layer (fp32 rows)
+    float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr;   // CLS-only last layer (fp32 rows)
     bool cls_prune = true;
     int* err_flag = nullptr;             // device word: bit 0 = a position outside [0, 1) was clamped (vtq_input_errors)
     std::vector<void*> ws_allocs;
@@ -275,7 +275,7 @@ size_t workspace_bytes(const vtq_engine* e, int B, int N) {
     b += (size_t)rows * Wmax * 2 * e->apl;                // qkv | mlp hidden | packed patches planes
     b += (size_t)P_pad * 4 * 3;                           // pos/scale indices, row map
     b += (size_t)2 * B * H * 4 * 6;                       // head ping-pong buffers (pairwise: 2 scores per item)
-    b += (size_t)2 * B * 4 * H * 4;                       // CLS-only last-layer rows (fp32)
+    b += (size_t)2 * B * 3 * H * 4;                       // CLS-only last-layer rows (fp32)
     const size_t ra = (size_t)round_up((int64_t)2 * B, 64);
     b += ra * (2 * H + e->hidp + H / 4) * 2 * 2;          // head planes (fp16 hi/lo)
     b += ra * (H + e->Mdim) * 2 * e->apl;                 // CLS-tail planes
@@ -304,7 +304,7 @@ int reserve(vtq_engine* e, int B, int N) {
     for (int i = 0; i < 5; ++i)
         if (dev_alloc(e, (void**)&e->hb[i], (size_t)2 * nB * H * 4, true)) return 1;
     if (dev_alloc(e, (void**)&e->xcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->lncls, (size_t)2 * nB * H * 4, true) ||
-        dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true) || dev_alloc(e, (void**)&e->acls, (size_t)2 * nB * H * 4, true))
+        dev_alloc(e, (void**)&e->qcls, (size_t)2 * nB * H * 4, true))
         return 1;
     {
         const int64_t ra = round_up((int64_t)2 * nB, 64);
@@ -358,7 +358,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     float* x = e->x;
     char* lnb = (char*)e->lnbuf;
     char* big = (char*)e->big;                               // QKV (ld 3H) and the MLP hidden (ld M) alias: never live together
-    float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls, *acls = e->acls;
+    float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls;
     const int64_t trace_stride = (int64_t)g.nseq * T * H;
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
@@ -384,22 +384,20 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
                     a.ya_planes = apl;
                     return a;
                 };
-                HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, s));
-                HIP_TRY(launch_rows_to_planes(lncls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                const PlaneOut tl{e->tl, e->tl_plane, H, f16, apl, nullptr};       // every row kernel of the tail writes its consumer's planes
+                HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, tl, s));
                 {   // query projection: rows 0 .. H-1 of the packed QKV weight
                     SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wqkv, Ly.pqkv, H, H, Ly.bqkv);
                     a.epi = SK_PLAIN; a.y = qcls; a.ldy = H; a.ycols = H;
                     HIP_TRY(launch_skinny(a, lin, s));
                 }
-                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, acls, R, g.S, g.S_pad, H, f16, apl, s));
-                HIP_TRY(launch_rows_to_planes(acls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, nullptr, R, g.S, g.S_pad, H, f16, apl, tl, s));
                 {   // out-proj + LayerScale + residual, in place on the CLS rows
                     SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wo, Ly.po, H, H, Ly.bo);
                     a.epi = SK_RESID; a.gamma = Ly.g1; a.res = xcls; a.ldr = H; a.y = xcls; a.ldy = H; a.ycols = H;
                     HIP_TRY(launch_skinny(a, lin, s));
                 }
-                HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, s));
-                HIP_TRY(launch_rows_to_planes(lncls, H, nullptr, e->tl, e->tl_plane, H, R, H, f16, apl, s));
+                HIP_TRY(launch_rows_ln(xcls, H, Ly.ln2w, Ly.ln2b, lncls, nullptr, R, H, tl, s));
                 {   // fc1 + GELU -> planes
                     SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.w1, Ly.p1, Md, H, Ly.b1);
                     a.epi = SK_GELU; a.ya = e->th; a.ya_plane = e->th_plane; a.ldya = Md;
@@ -449,12 +447,15 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     return 0;
 }
 
+// PReLU slope of the head's first consumer (the first RCAB), or NULL when there is no decoder
+const float* head_first_slope(const vtq_engine* e) { return (e->cfg.calibrate && !e->rgs.empty()) ? e->rgs[0].rcabs[0].slope : nullptr; }
+
 // DiffNet head + quality predictor on d[HB][H] (the CLS difference after diff_scale; vtamiq.py:111-117,
 // channel_attention.py:13-86) as a chain of skinny MFMA stages (skinny.hip), fp16 hi/lo operands, fp32 everywhere else.
 //   RCAB (channel_attention.py:41-50, 77-86) = two stages with the CA squeeze folded into the conv (launch_fold_ca):
 //     [c | t] = [Wc ; Wd Wc] prelu(r) + bcat, t = relu(.)        y = r + c * sigmoid(Wu t + bu)
 //   Every stage writes the planes its consumer reads, already passed through the consumer's PReLU.
-int run_head(vtq_engine* e, const float* d, int HB, float* q_out, hipStream_t s) {
+int run_head(vtq_engine* e, const float* d, int HB, float* q_out, hipStream_t s, bool planes_ready = false) {
     const vtq_config& c = e->cfg;
     const int H = e->H;
     const Num h3{1, 3};
@@ -466,8 +467,7 @@ int run_head(vtq_engine* e, const float* d, int HB, float* q_out, hipStream_t s)
         return a;
     };
     void *pin = e->hp[0], *pout = e->hp[1];
-    const float* first_slope = (c.calibrate && !e->rgs.empty()) ? e->rgs[0].rcabs[0].slope : nullptr;
-    HIP_TRY(launch_rows_to_planes(d, H, first_slope, pin, e->hp_plane, H, HB, H, 1, 2, s));
+    if (!planes_ready) HIP_TRY(launch_rows_to_planes(d, H, head_first_slope(e), pin, e->hp_plane, H, HB, H, 1, 2, s));
     if (c.calibrate) {
         const float* xr = d;                 // residual-group input (fp32)
         float* xr_buf[2] = {e->hb[1], e->hb[0]};      // d lives in hb[0]: the first RG writes hb[1]
@@ -687,9 +687,10 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     {
         Prof p(e, s, VTQ_K_HEAD);
         float* d = e->hb[0];
-        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, s));
-        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, s));
-        if (run_head(e, d, HB, q_out, s)) return 1;
+        const PlaneOut hp{e->hp[0], e->hp_plane, H, 1, 2, head_first_slope(e)};      // the first head stage's input planes
+        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, hp, s));
+        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s));
+        if (run_head(e, d, HB, q_out, s, true)) return 1;
     }
     return 0;
 }

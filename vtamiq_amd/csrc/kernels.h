@@ -33,6 +33,10 @@ enum { GEMM_FLAG_WRAP_ROWS = 1,     // every tile writes the rows of row panel 0
 struct SeqMap { int pitch, per, gap; };
 __host__ __device__ inline int64_t seq_row(const SeqMap& m, int s) { return (int64_t)s * m.pitch + (int64_t)(s / m.per) * m.gap; }
 
+// Optional 16-bit plane copy of a kernel's fp32 row output, in the form the next skinny stage reads (PReLU(*slope) first when
+// slope != NULL); p == NULL: none.
+struct PlaneOut { void* p; int64_t plane; int ld; int f16; int planes; const float* slope; };
+
 struct GemmArgs {
     const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
     const void* W; int64_t w_plane;               // bf16 planes [N, K]
@@ -84,7 +88,7 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 
 // d[j*B + b] = gamma * (LN(x[row(b)]) - LN(x[row((j+1)*B + b)])), j < ndist  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
-                             SeqMap sm, int H, hipStream_t s);
+                             SeqMap sm, int H, PlaneOut po, hipStream_t s);
 
 // one-time RCAB weight fold [Wc ; Wd Wc], bcat = [bc ; Wd bc + bd] (head.hip)
 hipError_t launch_fold_ca(const float* Wc, const float* bc, const float* Wd, const float* bd, float* Wcat, float* bcat, int H, int hid,
@@ -116,10 +120,10 @@ hipError_t launch_rows_to_planes(const float* x, int ldx, const float* slope, vo
 
 // ---- CLS-only tail of the last encoder layer (cls_tail.hip) -----------------------------------------------------------
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
-                          hipStream_t s);
+                          PlaneOut po, hipStream_t s);
 // K, V rows of the packed qkv planes (f16, planes); any S (the score buffer is dynamic LDS)
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int f16, int planes, hipStream_t s);
+                                int f16, int planes, PlaneOut po, hipStream_t s);
 // largest S launch_cls_attention accepts (LDS score buffer); longer sequences run the full last layer instead
 int cls_attention_max_seq();
 
@@ -134,5 +138,35 @@ hipError_t launch_gather_patches(const float* const* levels, const int* hs, cons
 hipError_t launch_repeat_mean(const float* q, double* out, int R, int N, hipStream_t s);
 hipError_t launch_rank_metrics(const double* a, const double* b, int N, int normalize, double* aa, double* bb, double* ra, double* rb,
                                long long* counts, double* out, hipStream_t s);
+
+#if defined(__HIPCC__) && defined(VTQ_DEV_COMMON)
+// 4 consecutive values of one row -> the plane sink (device side; dev_common.h must be included first)
+__device__ __forceinline__ void plane_store4(const PlaneOut& o, int64_t row, int col, float a, float b, float c, float d) {
+    if (!o.p) return;
+    if (o.slope) {
+        const float sl = *o.slope;
+        a = a >= 0.f ? a : sl * a; b = b >= 0.f ? b : sl * b; c = c >= 0.f ? c : sl * c; d = d >= 0.f ? d : sl * d;
+    }
+    if (o.f16) {
+        f16* dst = (f16*)o.p + row * o.ld + col;
+        if (o.planes == 1) *(f16x4*)dst = f16x4{(f16)a, (f16)b, (f16)c, (f16)d};
+        else {
+            f16x4 h, l; f16 x, y;
+            split2<f16>(a, x, y); h[0] = x; l[0] = y; split2<f16>(b, x, y); h[1] = x; l[1] = y;
+            split2<f16>(c, x, y); h[2] = x; l[2] = y; split2<f16>(d, x, y); h[3] = x; l[3] = y;
+            *(f16x4*)dst = h; *(f16x4*)(dst + o.plane) = l;
+        }
+    } else {
+        bf16* dst = (bf16*)o.p + row * o.ld + col;
+        if (o.planes == 1) *(bf16x4*)dst = bf16x4{(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+        else {
+            bf16x4 h, l; bf16 x, y;
+            split2<bf16>(a, x, y); h[0] = x; l[0] = y; split2<bf16>(b, x, y); h[1] = x; l[1] = y;
+            split2<bf16>(c, x, y); h[2] = x; l[2] = y; split2<bf16>(d, x, y); h[3] = x; l[3] = y;
+            *(bf16x4*)dst = h; *(bf16x4*)(dst + o.plane) = l;
+        }
+    }
+}
+#endif
 
 }  // namespace vtq

@@ -24,16 +24,16 @@ namespace {
 
 __device__ __forceinline__ float prelu1(float v, float a) { return v >= 0.f ? v : a * v; }
 
-template <typename T, int TERMS>
-__global__ __launch_bounds__(512) void skinny_linear_kernel(SkinnyArgs p) {
+template <typename T, int TERMS, int RB>      // RB = row blocks of 16 per workgroup: 64, 32 or 16 rows (the activation rows are the
+__global__ __launch_bounds__(512) void skinny_linear_kernel(SkinnyArgs p) {   // bulk of a workgroup's traffic: do not load more than R needs)
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
-    constexpr int APL = (TERMS == 1) ? 1 : 2, WPL = (TERMS == 3) ? 2 : 1, RB = 4, NW = 8, UN = 3;
+    constexpr int APL = (TERMS == 1) ? 1 : 2, WPL = (TERMS == 3) ? 2 : 1, NW = 8, UN = (RB == 4) ? 3 : 6;
     __shared__ __attribute__((aligned(16))) float red[NW][RB][64][4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * (16 * RB);
     const T* wrow = (const T*)p.W + (int64_t)(n0 + fr) * p.K + 8 * fq;
     const T* xrow = (const T*)p.xa + (int64_t)(r0 + fr) * p.ldx + 8 * fq;
     f32x4 acc[RB];
@@ -154,8 +154,14 @@ __global__ __launch_bounds__(256) void rows_to_planes_kernel(const float* __rest
 
 hipError_t launch_skinny(const SkinnyArgs& a, Num num, hipStream_t s) {
     if (a.R < 1 || a.N < 1 || a.K < 32 || a.K % 32 || a.ldx % 8 || (a.ya && (a.pcol0 % 4 || a.ldya % 4)) || !num_valid(num)) return hipErrorInvalidValue;
-    const dim3 g((a.N + 15) / 16, (a.R + 63) / 64), blk(512);
-#define VTQ_SK(TT, TM) hipLaunchKernelGGL((skinny_linear_kernel<TT, TM>), g, blk, 0, s, a)
+    const int rb = a.R <= 16 ? 1 : (a.R <= 32 ? 2 : 4);
+    const dim3 g((a.N + 15) / 16, (a.R + 16 * rb - 1) / (16 * rb)), blk(512);
+#define VTQ_SK(TT, TM)                                                                              \
+    do {                                                                                            \
+        if (rb == 1) hipLaunchKernelGGL((skinny_linear_kernel<TT, TM, 1>), g, blk, 0, s, a);        \
+        else if (rb == 2) hipLaunchKernelGGL((skinny_linear_kernel<TT, TM, 2>), g, blk, 0, s, a);   \
+        else hipLaunchKernelGGL((skinny_linear_kernel<TT, TM, 4>), g, blk, 0, s, a);                \
+    } while (0)
     if (!num.f16) { if (num.terms == 1) VTQ_SK(bf16, 1); else if (num.terms == 3) VTQ_SK(bf16, 3); else return hipErrorInvalidValue; }
     else { if (num.terms == 1) VTQ_SK(f16, 1); else if (num.terms == 2) VTQ_SK(f16, 2); else VTQ_SK(f16, 3); }
 #undef VTQ_SK
