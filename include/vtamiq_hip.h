@@ -34,6 +34,10 @@ extern "C" {
 #define VTQ_PREC_FP16X3 3   /* operands split hi+lo fp16, 3 MFMAs per product: at the fp32 reference's own noise floor         */
 #define VTQ_PREC_FP16X2 4   /* linear layers: activations split hi+lo fp16, weights single fp16 (2 MFMAs per product);         */
                             /* attention (QK^T, PV): the 3-term fp16 form                                                      */
+#define VTQ_PREC_FP8    5   /* BASELINE configs[4]: linear layers on OCP e4m3 operands with the MX-scaled MFMA (unit block      */
+                            /* scales, 2x the bf16 MFMA rate): weights e4m3 with per-output-channel power-of-two scales,         */
+                            /* activations e4m3 with static per-tensor scales; attention single fp16; head fp16 hi/lo.             */
+                            /* Checked against the fake-quant oracle (oracle/fp8_oracle.py), NOT within 1e-3 of the fp32 model. */
 
 /* operand-format code of the per-kernel entry points: MFMAs per product (1 | 2 | 3) + 16 for fp16 planes (0 = bf16):
  *   1 / 17 single plane each; 18 = activation hi/lo planes x single weight plane (fp16 only); 3 / 19 = hi/lo planes for both */
@@ -42,6 +46,7 @@ extern "C" {
 #define VTQ_NUM_FP16   17
 #define VTQ_NUM_FP16X2 18
 #define VTQ_NUM_FP16X3 19
+#define VTQ_NUM_FP8    33   /* e4m3 bytes, one plane each (vtq_k_gemm_fp8) */
 
 typedef struct vtq_config {
     int32_t hidden_size;       /* 768 | 1024                (transformer.py:68-98)                    */
@@ -113,6 +118,12 @@ int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors
  * vit_config["return_layers"] (transformer.py:369-372, 632-636). */
 int  vtq_set_token_trace(vtq_handle h, float* buf);
+/* Test hooks for localising a divergence: leave the encoder after stage `layer * 7 + k` of the NEXT forwards (k = 0 LayerNorm 1,
+ * 1 QKV, 2 attention, 3 out-proj, 4 LayerNorm 2, 5 fc1, 6 fc2; -1 = run everything; the scores of such a forward are
+ * meaningless), and borrow the workspace: x = fp32 residual stream [rows, H], lnbuf = LayerNorm / attention output planes,
+ * big = QKV / fc1 output planes, in the layouts DESIGN.md section 3 gives for the engine's precision. */
+int  vtq_debug_stop_after(vtq_handle h, int32_t stage);
+int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t* rows);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
 #define VTQ_K_CONVERT  0
@@ -143,6 +154,17 @@ int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int6
                 int32_t M, int32_t N, int32_t K, int32_t num, int32_t epilogue,
                 const float* bias, const float* gamma, float* x_f32,
                 void* out16, int64_t o_plane, int32_t ldo, void* stream);
+
+/* fp8 (VTQ_PREC_FP8) building blocks.  vtq_k_quant_rows_fp8: W[N][K] fp32 -> e4m3 rows, each scaled by the largest power of two
+ * that keeps its maximum <= 448, inv_scale[n] = 1 / scale.  vtq_k_quant_fp8: e4m3(src * scale), clamped to +-448.
+ * vtq_k_gemm_fp8: C = A8[M,K] * W8[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), acc * wscale[n] * ascale_inv,
+ * then the epilogue: 0 -> out = fp16 (one plane) of (v + bias); 1 -> out = e4m3(gelu(v + bias) * out_scale), ldo bytes per row;
+ * 2 -> x_f32 += gamma * (v + bias).  M%256==0, N%256==0, K%256==0. */
+int  vtq_k_quant_rows_fp8(const float* W, void* dst, float* inv_scale, int32_t N, int32_t K, void* stream);
+int  vtq_k_quant_fp8(const float* src, void* dst, int64_t numel, float scale, void* stream);
+int  vtq_k_gemm_fp8(const void* A8, int32_t lda, const void* W8, const float* wscale, float ascale_inv, int32_t M, int32_t N, int32_t K,
+                    int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out, int64_t o_plane, int32_t ldo,
+                    float out_scale, void* stream);
 
 /* HOST-only: the persistent schedule vtq_k_gemm uses for an [M, N] output (M, N multiples of 256) with K columns and `wplanes`
  * weight planes: out[0..256] = begin offsets of the 256 workgroups' lists (out[256] = total length), then the lists:

@@ -16,12 +16,15 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int v8i;
+struct f8 { uint8_t v; };      // one OCP e4m3 operand byte (the "fp8" numerics mode: MX-scaled MFMA with unit block scales)
 
 // 16-bit MFMA operand element: bf16 (8 significand bits, fp32 range) or f16 (11 bits, max 65504 -- the range the reference's
 // own GPU path runs these contractions in: torch.cuda.amp.autocast(float16), train.py:602).  Same MFMA rate on gfx950.
 template <typename T> struct Vec;
 template <> struct Vec<bf16> { typedef bf16x8 x8; typedef bf16x4 x4; };
 template <> struct Vec<f16> { typedef f16x8 x8; typedef f16x4 x4; };
+template <> struct Vec<f8> { typedef v8i x8; typedef uint32_t x4; };     // x8: one 16x16x128 MFMA fragment (32 bytes); x4: 4 packed bytes
 
 template <typename T>
 __device__ __forceinline__ f32x4 mfma16(typename Vec<T>::x8 a, typename Vec<T>::x8 b, f32x4 c) {
@@ -32,6 +35,22 @@ template <typename T>
 __device__ __forceinline__ f32x16 mfma32(typename Vec<T>::x8 a, typename Vec<T>::x8 b, f32x16 c) {
     if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// 16x16x128 e4m3 x e4m3 with unit block scales (E8M0 byte 127 = 2^0): twice the bf16 MFMA rate.  D rows come from the first
+// operand; both operands hold row (lane & 15), bytes 32 * (lane >> 4) .. + 31 of a K = 128 row (tools/micro/mx_probe.hip).
+__device__ __forceinline__ f32x4 mfma_f8(v8i a, v8i b, f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// 4 floats -> 4 e4m3 bytes (RNE, subnormals kept; the conversion turns |x| >= 464 into NaN, so clamp to the format's 448 first:
+// the same two steps as torch's clamp + .to(float8_e4m3fn) in oracle/fp8_oracle.py)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
 }
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))

@@ -8,9 +8,11 @@ namespace vtq {
 namespace {
 
 template <typename T, int NPL>
-__device__ __forceinline__ void store4(T* dst, int64_t plane, float a, float b, float c, float d) {
+__device__ __forceinline__ void store4(T* dst, int64_t plane, float a, float b, float c, float d, float scale = 1.0f) {
     typedef typename Vec<T>::x4 tx4;
-    if constexpr (NPL == 1) {
+    if constexpr (std::is_same<T, f8>::value) {          // e4m3 bytes of value * scale (static per-tensor scale, fp8 mode)
+        *(uint32_t*)dst = pack_fp8x4(a * scale, b * scale, c * scale, d * scale);
+    } else if constexpr (NPL == 1) {
         tx4 h = {(T)a, (T)b, (T)c, (T)d};
         *(tx4*)dst = h;
     } else {
@@ -27,11 +29,37 @@ __device__ __forceinline__ void store4(T* dst, int64_t plane, float a, float b, 
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t plane,
-                                                    int64_t n4) {
+                                                    int64_t n4, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = ((const float4*)src)[i];
-        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w, scale);
     }
+}
+
+// fp8 weights: one wave per row of W[N][K]: s = the largest power of two with max|row| * s <= 448 (1 for an all-zero row),
+// dst = e4m3(W * s), inv_scale[n] = 1 / s   (per-output-channel scale; oracle/fp8_oracle.py quant_rows)
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst,
+                                                             float* __restrict__ inv_scale, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float4* row = (const float4*)(src + (int64_t)n * K);
+    float mx = 0.f;
+    for (int i = lane; i < K / 4; i += 64) {
+        const float4 v = row[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 1.0f;
+    if (mx > 0.f) s = exp2f(floorf(log2f(448.0f / mx)));
+    if (mx * s > 448.0f) s *= 0.5f;                       // log2f rounding next to an exact power of two, either side
+    else if (mx > 0.f && mx * s * 2.0f <= 448.0f) s *= 2.0f;
+    for (int i = lane; i < K / 4; i += 64) {
+        const float4 v = row[i];
+        ((uint32_t*)(dst + (int64_t)n * K))[i] = pack_fp8x4(v.x * s, v.y * s, v.z * s, v.w * s);
+    }
+    if (lane == 0) inv_scale[n] = 1.0f / s;
 }
 
 // rows [k*BN, (k+1)*BN) from image k (k < nimg: ref, dist[, dist2]); rows >= nimg*BN zero.  K = 768 floats per row.
@@ -39,7 +67,7 @@ struct ImgPtrs { const float* p[3]; };
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, T* __restrict__ dst, int64_t plane, int BN, int K4,
-                                                           int64_t total4) {
+                                                           int64_t total4, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / K4;
         const int c4 = (int)(i - row * K4);
@@ -49,7 +77,7 @@ __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg
             const float* sp = img == 0 ? src.p[0] : (img == 1 ? src.p[1] : src.p[2]);
             v = ((const float4*)sp)[(row - (int64_t)img * BN) * K4 + c4];
         }
-        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w);
+        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w, scale);
     }
 }
 
@@ -153,7 +181,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
 template <int V4, typename T, int NPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ out, int64_t o_plane,
-                                                        int rows) {
+                                                        int rows, float scale) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     ln_row<V4>(x + (int64_t)row * H, w, b, lane, y);
     T* o = out + (int64_t)row * H;
 #pragma unroll
-    for (int i = 0; i < V4; ++i) store4<T, NPL>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w);
+    for (int i = 0; i < V4; ++i) store4<T, NPL>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w, scale);
 }
 
 // encoder_norm on the two CLS rows of pair b only (transformer.py:376 applies it to all rows; only token 0 is
@@ -201,27 +229,34 @@ inline int grid_for(int64_t work, int block) {
     do {                                                        \
         if (!(f16_) && (npl_) == 1) { CALL(bf16, 1); }          \
         else if (!(f16_) && (npl_) == 2) { CALL(bf16, 2); }     \
-        else if ((f16_) && (npl_) == 1) { CALL(f16, 1); }       \
-        else if ((f16_) && (npl_) == 2) { CALL(f16, 2); }       \
+        else if ((f16_) == 1 && (npl_) == 1) { CALL(f16, 1); }  \
+        else if ((f16_) == 1 && (npl_) == 2) { CALL(f16, 2); }  \
+        else if ((f16_) == 2 && (npl_) == 1) { CALL(f8, 1); }   \
         else return hipErrorInvalidValue;                       \
     } while (0)
 
-hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s) {
+hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s) {
+    if (K % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, src, (uint8_t*)dst, inv_scale, N, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s, float scale) {
     if (numel % 4) return hipErrorInvalidValue;
     const int64_t n4 = numel / 4;
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((split_kernel<TT, NP>), dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (TT*)dst, plane, n4)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((split_kernel<TT, NP>), dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (TT*)dst, plane, n4, scale)
     VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     return hipGetLastError();
 }
 
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16_,
-                               int planes, hipStream_t s) {
+                               int planes, hipStream_t s, float scale) {
     const int K4 = K / 4;
     const int64_t total4 = (int64_t)rows_pad * K4;
     ImgPtrs ip{{imgs[0], imgs[1], nimg > 2 ? imgs[2] : nullptr}};
 #define VTQ_CALL(TT, NP) \
-    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, total4)
+    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, total4, scale)
     VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     return hipGetLastError();
@@ -256,14 +291,14 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int f16_, int planes, hipStream_t s) {
+                            int f16_, int planes, hipStream_t s, float scale) {
     const dim3 g((rows + 3) / 4), blk(256);
     if (H == 768) {
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<3, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<3, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale)
         VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     } else if (H == 1024) {
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<4, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<4, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale)
         VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     } else return hipErrorInvalidValue;

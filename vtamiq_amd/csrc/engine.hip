@@ -41,17 +41,25 @@ int fail(const char* fmt, ...) {
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// fp8 mode: static power-of-two activation scales (value * scale is rounded to e4m3, |.| clamped to 448); oracle/fp8_oracle.py
+// carries the same constants.  patches in [-1, 1]; LayerNorm outputs up to ~sqrt(H) * |weight|; attention outputs are convex
+// combinations of V rows; GELU outputs follow the fc1 range.
+constexpr float kSPatch = 256.0f, kSLn = 8.0f, kSAtt = 16.0f, kSGelu = 4.0f;
+
 struct Slot {
     void* dst = nullptr;      // destination (fp32 copy) or bf16 hi plane (split)
     int64_t numel = 0;
-    bool split = false;       // true: pack to 16-bit planes (engine->f16, engine->wpl)
+    bool split = false;       // true: pack to 16-bit planes (engine->f16, engine->wpl), or to e4m3 rows + per-row scales (fp8 mode)
     int64_t plane = 0;        // elements between hi and lo plane
+    float* scale = nullptr;   // fp8 mode: destination of the rows' inverse scales
+    int64_t K = 0;            // row length of a split tensor
     bool loaded = false;
 };
 
 struct Layer {
-    void *wqkv, *wo, *w1, *w2;                 // bf16 planes
+    void *wqkv, *wo, *w1, *w2;                 // 16-bit planes / e4m3 rows
     int64_t pqkv, po, p1, p2;                  // plane strides
+    float *sqkv, *so, *s1, *s2;                // fp8 mode: per-output-channel inverse weight scales
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b, *g1, *g2;
 };
 // One linear stage of the DiffNet head as the skinny-MFMA kernel reads it: fp16 hi/lo planes [2][ceil16(N)][Kp] (Kp = K padded
@@ -66,6 +74,9 @@ struct vtq_engine {
     vtq_config cfg{};
     Num lin{0, 1}, att{0, 1};          // operand format of the linear layers / of attention (QK^T, PV)
     int f16 = 0, apl = 1, wpl = 1;     // element type of every plane; planes per activation / per weight tensor
+    int dbg_stop = -1;                 // tests: leave the encoder after stage layer * 7 + k (vtq_debug_stop_after), -1 = never
+    bool fp8 = false;                  // linear layers on e4m3 operands (MX-scaled MFMA, unit block scales): VTQ_PREC_FP8
+    float* spatch = nullptr;           //   inverse weight scales of the patch embedding
     int H = 0, Mdim = 0, T = 0;
     std::vector<void*> allocs;
     std::unordered_map<std::string, Slot> slots;
@@ -121,9 +132,11 @@ int add_f32(vtq_engine* e, const std::string& name, float** p, int64_t numel) {
     return 0;
 }
 
-// bf16 planes for a [rows_total, K] weight; sub-slot `name` covers rows [row0, row0 + rows)
-int add_split(vtq_engine* e, const std::string& name, void* base, int64_t plane, int64_t row0, int64_t rows, int64_t K) {
-    Slot s; s.dst = (char*)base + row0 * K * 2; s.numel = rows * K; s.split = true; s.plane = plane;
+// planes (or e4m3 rows) for a [rows_total, K] weight; sub-slot `name` covers rows [row0, row0 + rows)
+int add_split(vtq_engine* e, const std::string& name, void* base, int64_t plane, int64_t row0, int64_t rows, int64_t K,
+              float* scale_base = nullptr) {
+    Slot s; s.dst = (char*)base + row0 * K * (e->fp8 ? 1 : 2); s.numel = rows * K; s.split = true; s.plane = plane; s.K = K;
+    s.scale = scale_base ? scale_base + row0 : nullptr;
     e->slots[name] = s;
     return 0;
 }
@@ -140,7 +153,8 @@ int build(vtq_engine* e) {
     if (add_f32(e, emb + "cls_token", &e->cls, H)) return 1;
     if (c.num_extra_tokens > 0 && add_f32(e, emb + "extra_tokens", &e->extra, (int64_t)c.num_extra_tokens * H)) return 1;
     if (alloc_planes(e, &e->wpatch, &e->ppatch, H * PD)) return 1;
-    add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD);
+    if (e->fp8 && dev_alloc(e, (void**)&e->spatch, H * sizeof(float))) return 1;
+    add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD, e->spatch);
     if (add_f32(e, emb + "patch_embeddings.bias", &e->bpatch, H)) return 1;
     if (add_f32(e, emb + "positional_embeddings.positional_embeddings", &e->pos_table, ((int64_t)c.pos_grid * c.pos_grid + 1) * H))
         return 1;
@@ -157,15 +171,18 @@ int build(vtq_engine* e) {
             alloc_planes(e, &L.w1, &L.p1, M * H) || alloc_planes(e, &L.w2, &L.p2, H * M))
             return 1;
         if (dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float))) return 1;
+        if (e->fp8 && (dev_alloc(e, (void**)&L.sqkv, 3 * H * sizeof(float)) || dev_alloc(e, (void**)&L.so, H * sizeof(float)) ||
+                       dev_alloc(e, (void**)&L.s1, M * sizeof(float)) || dev_alloc(e, (void**)&L.s2, H * sizeof(float))))
+            return 1;
         const char* qkvn[3] = {"query", "key", "value"};
         for (int j = 0; j < 3; ++j) {
-            add_split(e, p + "attn." + qkvn[j] + ".weight", L.wqkv, L.pqkv, j * H, H, H);
+            add_split(e, p + "attn." + qkvn[j] + ".weight", L.wqkv, L.pqkv, j * H, H, H, L.sqkv);
             Slot s; s.dst = L.bqkv + j * H; s.numel = H;
             e->slots[p + "attn." + qkvn[j] + ".bias"] = s;
         }
-        add_split(e, p + "attn.out.weight", L.wo, L.po, 0, H, H);
-        add_split(e, p + "ffn.fc1.weight", L.w1, L.p1, 0, M, H);
-        add_split(e, p + "ffn.fc2.weight", L.w2, L.p2, 0, H, M);
+        add_split(e, p + "attn.out.weight", L.wo, L.po, 0, H, H, L.so);
+        add_split(e, p + "ffn.fc1.weight", L.w1, L.p1, 0, M, H, L.s1);
+        add_split(e, p + "ffn.fc2.weight", L.w2, L.p2, 0, H, M, L.s2);
         if (add_f32(e, p + "attn.out.bias", &L.bo, H) || add_f32(e, p + "ffn.fc1.bias", &L.b1, M) ||
             add_f32(e, p + "ffn.fc2.bias", &L.b2, H) || add_f32(e, p + "attention_norm.weight", &L.ln1w, H) ||
             add_f32(e, p + "attention_norm.bias", &L.ln1b, H) || add_f32(e, p + "ffn_norm.weight", &L.ln2w, H) ||
@@ -411,37 +428,52 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             }
             break;
         }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
+        // fp8 mode (VTQ_PREC_FP8): LayerNorm / attention / GELU outputs are e4m3 bytes with the static scales kS*, weights are
+        // e4m3 rows with per-output-channel scales (de-scaled in the GEMM epilogue); the QKV output is one fp16 plane
+        const bool f8m = e->fp8;
+        const int lnf = f8m ? 2 : f16, lnp = f8m ? 1 : apl;
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
+        if (e->dbg_stop == i * 7 + 0) return 0;
         {
             Prof p(e, s, VTQ_K_QKV);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
             a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = big; a.o_plane = e->big_plane; a.ldo = 3 * H;
+            a.wscale = Ly.sqkv; a.ascale_inv = 1.0f / kSLn;
             HIP_TRY(launch_gemm(a, lin, EPI_BIAS, s));
         }
-        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s)); }
+        if (e->dbg_stop == i * 7 + 1) return 0;
+        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, f8m ? kSAtt : 0.0f)); }
+        if (e->dbg_stop == i * 7 + 2) return 0;
         {
             Prof p(e, s, VTQ_K_OUTPROJ);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
             a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = x;
+            a.wscale = Ly.so; a.ascale_inv = 1.0f / kSAtt;
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
         }
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, f16, apl, s)); }
+        if (e->dbg_stop == i * 7 + 3) return 0;
+        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
+        if (e->dbg_stop == i * 7 + 4) return 0;
         {
             Prof p(e, s, VTQ_K_FC1);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
             a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = big; a.o_plane = e->big_plane; a.ldo = Md;
+            a.wscale = Ly.s1; a.ascale_inv = 1.0f / kSLn; a.out_scale = kSGelu;
             HIP_TRY(launch_gemm(a, lin, EPI_BIAS_GELU, s));
         }
+        if (e->dbg_stop == i * 7 + 5) return 0;
         {
             Prof p(e, s, VTQ_K_FC2);
             GemmArgs a{};
             a.A = big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
             a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = x;
+            a.wscale = Ly.s2; a.ascale_inv = 1.0f / kSGelu;
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
         }
+        if (e->dbg_stop == i * 7 + 6) return 0;
         if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride, g.nseq, g.sm, T, H, s));
     }
     return 0;
@@ -552,10 +584,11 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
         case VTQ_PREC_FP16:   e->lin = Num{1, 1}; e->att = Num{1, 1}; break;
         case VTQ_PREC_FP16X3: e->lin = Num{1, 3}; e->att = Num{1, 3}; break;
         case VTQ_PREC_FP16X2: e->lin = Num{1, 2}; e->att = Num{1, 3}; break;     // attention keeps the 3-term form
+        case VTQ_PREC_FP8:    e->lin = Num{2, 1}; e->att = Num{1, 1}; e->fp8 = true; break;   // e4m3 linears, single-fp16 attention (2e-4 << the e4m3 step)
         default: delete e; return fail("unknown precision %d", c.precision);
     }
-    e->f16 = e->lin.f16;
-    e->apl = e->lin.apl();
+    e->f16 = e->fp8 ? 1 : e->lin.f16;          // fp8 mode: the QKV output is one fp16 plane (buffers are sized for it);
+    e->apl = e->fp8 ? 1 : e->lin.apl();        //   LayerNorm / GELU / attention outputs are e4m3 bytes
     e->wpl = e->lin.wpl();
     e->H = c.hidden_size;
     e->Mdim = c.mlp_dim;
@@ -591,7 +624,8 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         if (it == e->slots.end()) return fail("vtq_load_weights: unexpected tensor '%s'", d.name);
         Slot& sl = it->second;
         if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
-        if (sl.split) HIP_TRY(launch_split(d.data, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
+        if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(d.data, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s));
+        else if (sl.split) HIP_TRY(launch_split(d.data, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
         else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
     }
@@ -610,6 +644,21 @@ int vtq_reserve(vtq_handle e, int32_t B, int32_t N) {
 int vtq_set_token_trace(vtq_handle e, float* buf) {
     if (!e) return fail("null handle");
     e->trace = buf;
+    return 0;
+}
+
+int vtq_debug_stop_after(vtq_handle e, int32_t stage) {
+    if (!e) return fail("null handle");
+    e->dbg_stop = stage;
+    return 0;
+}
+
+int vtq_debug_buffers(vtq_handle e, void** x, void** lnbuf, void** big, int64_t* rows) {
+    if (!e || !e->x) return fail("vtq_debug_buffers: no workspace yet (run a forward first)");
+    if (x) *x = e->x;
+    if (lnbuf) *lnbuf = e->lnbuf;
+    if (big) *big = e->big;
+    if (rows) *rows = e->ln_plane / e->H;
     return 0;
 }
 
@@ -658,7 +707,8 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
-        HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s));
+        if (e->fp8) HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, 2, 1, s, kSPatch));
+        else HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s));
         HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
                                    c.pos_grid, c.num_scales, e->err_flag, s));
         HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
@@ -673,6 +723,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         a.bias = e->bpatch; a.x = e->x;
         a.row_map = e->row_map; a.idx1 = e->pidx; a.table1 = e->pos_table;
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
+        a.wscale = e->spatch; a.ascale_inv = 1.0f / kSPatch;
         HIP_TRY(launch_gemm(a, e->lin, EPI_EMBED, s));
     }
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
@@ -680,7 +731,8 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
     // the trace tap needs every token row of the last layer; sequences longer than the CLS kernel's LDS score buffer run the
     // full last layer instead (same result)
-    const bool prune = e->cls_prune && !e->trace && g.S <= cls_attention_max_seq();
+    // (fp8 mode runs the full last layer: its CLS row then goes through the same e4m3 GEMMs as every other row)
+    const bool prune = e->cls_prune && !e->trace && !e->fp8 && g.S <= cls_attention_max_seq();
     if (run_encoder(e, g, s, prune)) return 1;
 
     // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------
@@ -745,6 +797,28 @@ int vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64
     a.A = A; a.a_plane = a_plane; a.lda = lda; a.W = W; a.w_plane = w_plane; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.gamma = gamma; a.x = x_f32; a.out = out16; a.o_plane = o_plane; a.ldo = ldo;
     HIP_TRY(launch_gemm(a, nm, epilogue, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_quant_rows_fp8(const float* W, void* dst, float* inv_scale, int32_t N, int32_t K, void* stream) {
+    if (!W || !dst || !inv_scale || N < 1 || K < 4) return fail("vtq_k_quant_rows_fp8: bad argument");
+    HIP_TRY(launch_quant_rows_fp8(W, dst, inv_scale, N, K, (hipStream_t)stream));
+    return 0;
+}
+
+int vtq_k_quant_fp8(const float* src, void* dst, int64_t numel, float scale, void* stream) {
+    HIP_TRY(launch_split(src, dst, 0, numel, 2, 1, (hipStream_t)stream, scale));
+    return 0;
+}
+
+int vtq_k_gemm_fp8(const void* A8, int32_t lda, const void* W8, const float* wscale, float ascale_inv, int32_t M, int32_t N, int32_t K,
+                   int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out, int64_t o_plane, int32_t ldo,
+                   float out_scale, void* stream) {
+    if (epilogue < 0 || epilogue > 2) return fail("vtq_k_gemm_fp8: epilogue %d", epilogue);
+    GemmArgs a{};
+    a.A = A8; a.lda = lda; a.W = W8; a.M = M; a.N = N; a.K = K; a.bias = bias; a.gamma = gamma; a.x = x_f32; a.out = out; a.o_plane = o_plane;
+    a.ldo = ldo; a.wscale = wscale; a.ascale_inv = ascale_inv; a.out_scale = out_scale;
+    HIP_TRY(launch_gemm(a, Num{2, 1}, epilogue, (hipStream_t)stream));
     return 0;
 }
 

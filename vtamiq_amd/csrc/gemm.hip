@@ -69,10 +69,35 @@ template <int OPL, int EPI, int MH> constexpr int epilogue_vmem_ops() {
     return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? MH * 2 * OPL * 4 : MH * 4 * 8;
 }
 
-template <typename T, int OPL, int EPI, int MH>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
+template <typename T, int OPL, int EPI, int MH> constexpr int epilogue_ops_of() {     // T = OUTPUT element type
+    return std::is_same<T, f8>::value ? ((EPI == EPI_BIAS_GELU) ? MH * 2 * 2 : epilogue_vmem_ops<OPL, EPI, MH>()) : epilogue_vmem_ops<OPL, EPI, MH>();
+}
+
+// T = OUTPUT element type of the 16-bit / 8-bit forms; SCALED: fp8 operands (acc * wscale[n] * ascale_inv before the bias)
+template <typename T, int OPL, int EPI, int MH, bool SCALED>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
                                             int fr, int fq, int64_t m0, int n0) {
     typedef typename Vec<T>::x4 tx4;
+    // opaque copies of the lane indices: every per-lane address below is then formed HERE, after the main loop, instead of being
+    // hoisted above it and kept (or spilled) across it
+    asm volatile("" : "+v"(tid), "+v"(fr), "+v"(fq));
+    if constexpr (SCALED) {           // de-scale the accumulators once, in place: the forms below then see plain values
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int n = n0 + nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                float4 s4 = *(const float4*)(p.wscale + n);
+                s4.x *= p.ascale_inv; s4.y *= p.ascale_inv; s4.z *= p.ascale_inv; s4.w *= p.ascale_inv;
+#pragma unroll
+                for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        f32x4& a = acc[mh][nh][mi][ni];
+                        a[0] *= s4.x; a[1] *= s4.y; a[2] *= s4.z; a[3] *= s4.w;
+                    }
+            }
+    }
     // acc[mh][nh][mi][ni][reg]: m = m0 + mh*128 + wr*64 + mi*16 + fr ; n = n0 + nh*128 + wc*32 + ni*16 + fq*4 + reg
     // 16-bit outputs and the fp32 residual update go through LDS (free after the main loop) so that every global access is a
     // full row segment: one wave instruction = 2 rows x 512 B (16-bit) or 1 row x 1 KiB (fp32), 16 bytes per lane.
@@ -94,7 +119,54 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if constexpr ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && std::is_same<T, f8>::value) {
+        // e4m3 output (the GELU form of the fp8 mode): chunk (mh, q) as below, image rows of 256 bytes, one pass per chunk
+        constexpr int RS = 272;                         // 256 B + 16 B pad
+        constexpr int IMG = 64 * RS;
+        constexpr int NPASS = MH * 2;
+        auto convert = [&](int pass) {
+            const int mh = pass >> 1, q = pass & 1;
+            char* img = smem + STG + (pass & 1) * IMG;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int lrow = wr * 32 + e * 16 + fr;
+                        const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                        const f32x4 a = acc[mh][nh][2 * q + e][ni];
+                        const float4 bb = b4[nh][ni];
+                        float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
+                        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+                        }
+                        *(uint32_t*)(img + lrow * RS + col) = pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
+                    }
+        };
+        auto copy_out = [&](int pass) {
+            const int mh = pass >> 1, q = pass & 1;
+            const char* img = smem + STG + (pass & 1) * IMG;
+            const int c16 = tid & 15, r0 = tid >> 4;    // 16 threads x 16 B per 256-byte row, 32 rows per sweep
+            char* og = (char*)p.out + m0 * p.ldo + n0 + c16 * 16;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {            // image row ps*32 + r0 = (wr = ps, e = r0 >> 4, fr = r0 & 15)
+                const int grow = mh * 128 + ps * 64 + (2 * q + (r0 >> 4)) * 16 + (r0 & 15);
+                const uint4 v = *(const uint4*)(img + (ps * 32 + r0) * RS + c16 * 16);
+                store_nt16(og + (int64_t)grow * p.ldo, v);
+            }
+        };
+        convert(0);
+        interval_end();
+#pragma unroll
+        for (int pass = 1; pass < NPASS; ++pass) {
+            if (wr == 0) { copy_out(pass - 1); convert(pass); }
+            else { convert(pass); copy_out(pass - 1); }
+            interval_end();
+        }
+        copy_out(NPASS - 1);
+    } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // chunk (mh, q): the 64 rows {mh*128 + wr*64 + (2q + e)*16 + fr}, image row = wr*32 + e*16 + fr; one pass per plane
         constexpr int RS = 528;                         // 256 x 16 bit + 16 B pad: rows stay 16-B aligned for ds_read_b128
         constexpr int IMG = 64 * RS;
@@ -265,15 +337,18 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 // workgroup's list (build_schedule) and take no part in the cross-tile prefetch.
 template <typename T, int TERMS, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
-    typedef typename Vec<T>::x8 tx8;
-    constexpr int BK = (TERMS == 1) ? 64 : 32;
-    constexpr int ROWB = BK * 2;
+    typedef typename Vec<T>::x8 tx8;                 // one MFMA operand fragment: 16 bytes (16-bit forms) / 32 bytes (fp8)
+    constexpr bool F8 = std::is_same<T, f8>::value;
+    static_assert(!F8 || TERMS == 1, "fp8 operands are single-plane");
+    constexpr int ES = F8 ? 1 : 2;                   // bytes per operand element
+    constexpr int BK = F8 ? 128 : ((TERMS == 1) ? 64 : 32);
+    constexpr int ROWB = BK * ES;                    // bytes of a K-tile row: 128 (one plane, fp8 too) | 64
     constexpr int APL = (TERMS == 1) ? 1 : 2;        // activation planes (also the planes of a 16-bit output)
     constexpr int REG_B = 16384;                     // one half-tile region (A: all planes; W with one plane of BK = 32 fills half)
     constexpr int BUF_B = 4 * REG_B;                 // one K tile: regions 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
     constexpr int NA = 2, NW = (TERMS == 2) ? 1 : 2; // LDS-DMA instructions per wave per A / W region
     constexpr int GE = NA + 2 * NW, GO = NA;
-    constexpr int NFA = 8, NFB = (TERMS == 2) ? 2 : 4;
+    constexpr int NFA = F8 ? 4 : 8, NFB = (F8 || TERMS == 2) ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -282,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     // Per-lane addressing state.  It is RE-DERIVED at the top of every tile (tile_setup) from an opaque copy of the thread id,
     // so that none of it stays live across the epilogue, whose accumulators + staging values already fill the register file.
     int tid, fr, fq;
-    uint32_t a_off[2], w_off[2];     // DMA source byte offsets inside a half-tile plane (two rounds of 512 x 16 B; 2 planes: one round each)
+    uint32_t a_off_, w_off_;         // DMA source byte offset of this thread inside a half-tile plane (first of its two 16-byte pieces)
     int a_rd[2], b_rd[2];            // fragment read offsets inside a region: x = k-step (TERMS 1) or plane (TERMS 2, 3)
     auto tile_setup = [&]() {
         tid = threadIdx.x;
@@ -290,23 +365,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         const int lane = tid & 63;
         fr = lane & 15;
         fq = lane >> 4;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if constexpr (TERMS == 1) {
-                const int slot = r * 512 + tid;
-                const int row = slot >> 3, c = (slot & 7) ^ swz<64>(row);
-                a_off[r] = (uint32_t)(row * p.lda + c * 8) * 2u;
-                w_off[r] = (uint32_t)(row * p.K + c * 8) * 2u;
-            } else {
-                const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);
-                a_off[r] = (uint32_t)(row * p.lda + c * 8) * 2u;
-                w_off[r] = (uint32_t)(row * p.K + c * 8) * 2u;
-            }
+        if constexpr (TERMS == 1) {          // piece r = rows r*64 + (tid >> 3): the second piece is 64 rows further (same swizzle)
+            const int row = tid >> 3, c = (tid & 7) ^ swz<64>(row);
+            a_off_ = (uint32_t)(row * p.lda * ES + c * 16);
+            w_off_ = (uint32_t)(row * p.K * ES + c * 16);
+        } else {                             // piece r = plane r: same offset, the plane stride goes on the scalar base
+            const int row = tid >> 2, c = (tid & 3) ^ swz<32>(row);
+            a_off_ = (uint32_t)(row * p.lda + c * 8) * 2u;
+            w_off_ = (uint32_t)(row * p.K + c * 8) * 2u;
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             if constexpr (TERMS == 1) {
-                const int ch = ((x * 4 + fq) ^ swz<64>(fr)) << 4;
+                // 16-bit: x = k-step (lane group fq takes chunk 4x + fq); fp8: the two chunks of the lane's 32 bytes (2 fq + x)
+                const int ch = ((F8 ? (2 * fq + x) : (x * 4 + fq)) ^ swz<64>(fr)) << 4;
                 a_rd[x] = (wr * 64 + fr) * ROWB + ch;
                 b_rd[x] = (wc * 32 + fr) * ROWB + ch;
             } else {
@@ -316,8 +388,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
         }
     };
-    // plane strides in bytes (wave-uniform: they go on the scalar base of a DMA, the per-lane part stays 32 bit)
-    const int64_t a_pl = (TERMS == 1) ? 0 : p.a_plane * 2, w_pl = (TERMS == 3) ? p.w_plane * 2 : 0;
+    // byte distance (wave-uniform) from a thread's first DMA piece to its second: 64 rows on (one plane) or one plane on
+    const int64_t a_d2 = (TERMS == 1) ? (int64_t)64 * p.lda * ES : p.a_plane * 2;
+    const int64_t w_d2 = (TERMS == 1) ? (int64_t)64 * p.K * ES : ((TERMS == 3) ? p.w_plane * 2 : 0);
     f32x4 acc[2][2][4][2];
     tx8 fa[NFA], fb0[NFB], fb1[NFB];
     auto zero_acc = [&]() {
@@ -330,16 +403,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
+    typedef __attribute__((ext_vector_type(4))) int v4i;
+    auto read32 = [&](const char* a0, const char* a1) {      // fp8 fragment: two 16-byte chunks of one row
+        const v4i lo = *(const v4i*)a0, hi = *(const v4i*)a1;
+        return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
     auto read_a = [&](const char* reg) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (F8) fa[i] = read32(reg + a_rd[0] + i * 16 * ROWB, reg + (a_rd[0] ^ 16) + i * 16 * ROWB);   // chunks 2fq, 2fq+1: the XOR swizzle keeps them 16 B apart
+            else {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const tx8*)(reg + a_rd[x] + i * 16 * ROWB);
+                for (int x = 0; x < 2; ++x) fa[i * 2 + x] = *(const tx8*)(reg + a_rd[x] + i * 16 * ROWB);
+            }
+        }
     };
     auto read_b = [&](const char* reg, tx8(&fb)[NFB]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if constexpr (TERMS == 2) fb[j] = *(const tx8*)(reg + b_rd[0] + j * 16 * ROWB);
+            if constexpr (F8) fb[j] = read32(reg + b_rd[0] + j * 16 * ROWB, reg + (b_rd[0] ^ 16) + j * 16 * ROWB);
+            else if constexpr (TERMS == 2) fb[j] = *(const tx8*)(reg + b_rd[0] + j * 16 * ROWB);
             else {
 #pragma unroll
                 for (int x = 0; x < 2; ++x) fb[j * 2 + x] = *(const tx8*)(reg + b_rd[x] + j * 16 * ROWB);
@@ -351,7 +434,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (TERMS == 1) {
+                if constexpr (F8) {
+                    c[i][j] = mfma_f8(fb[j], fa[i], c[i][j]);
+                } else if constexpr (TERMS == 1) {
                     c[i][j] = mfma16<T>(fb[j * 2 + 0], fa[i * 2 + 0], c[i][j]);
                     c[i][j] = mfma16<T>(fb[j * 2 + 1], fa[i * 2 + 1], c[i][j]);
                 } else if constexpr (TERMS == 2) {
@@ -369,14 +454,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         char* dst = smem + (kt & 1) * BUF_B + r * REG_B + wave * 1024;
         const bool isA = (r == 0 || r == 3);
         const int half = (r >= 2) ? 1 : 0;
+        // the per-lane part stays a 32-bit offset next to a scalar base (opaque here: otherwise hipcc pre-adds it to every
+        // tile base as 64-bit VGPR pairs that live -- or spill -- across the K loop)
+        uint32_t a_off = a_off_, w_off = w_off_;
+        asm volatile("" : "+v"(a_off), "+v"(w_off));
         if (isA) {
             const char* base = (const char*)(ag + (int64_t)half * kHalfRows * p.lda + kt * BK);
-            glds16(base + a_off[0], dst);
-            glds16(base + a_pl + a_off[1], dst + 8192);
+            glds16(base + a_off, dst);
+            glds16(base + a_d2 + a_off, dst + 8192);
         } else {
             const char* base = (const char*)(wg + (int64_t)half * kHalfRows * p.K + kt * BK);
-            glds16(base + w_off[0], dst);
-            if constexpr (NW == 2) glds16(base + w_pl + w_off[1], dst + 8192);
+            glds16(base + w_off, dst);
+            if constexpr (NW == 2) glds16(base + w_d2 + w_off, dst + 8192);
         }
     };
 
@@ -392,7 +481,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                              \
     __builtin_amdgcn_sched_barrier(0);
 
-    constexpr int EOPS = epilogue_vmem_ops<APL, EPI, 2>();
+    // output form: the operand type's planes; fp8 operands: BIAS -> fp16 hi/lo planes (attention input), GELU -> e4m3 bytes
+    typedef typename std::conditional<F8, typename std::conditional<EPI == EPI_BIAS_GELU, f8, f16>::type, T>::type TO;
+    constexpr int OPL = F8 ? 1 : APL;      // fp8 mode: one fp16 plane (QKV -> single-MFMA attention) or e4m3 bytes (GELU)
+    constexpr int EOPS = epilogue_ops_of<TO, OPL, EPI, 2>();
     constexpr int NCHAIN = (EOPS + GE > 63) ? 63 : EOPS + GE;   // youngest ops that may stay in flight while g0/g1 of a chained tile are waited for
     constexpr bool kChain = (EPI != EPI_EMBED);                 // cross-tile DMA chaining (EMBED's stores are conditional: not countable)
     // the schedule is read through the scalar cache (constant address space): a vector load here would make hipcc drain
@@ -475,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
             if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
             if (!(p.flags & GEMM_FLAG_NO_EPILOGUE))
-                pp_epilogue<T, APL, EPI, 2>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+                pp_epilogue<TO, OPL, EPI, 2, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
             else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
@@ -495,16 +587,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             constexpr int BUF_H = 3 * REG_B;
             constexpr int GH = NA + 2 * NW;
             auto stage_h = [&](int kt, int slot) {             // {A0, W0, W1} of K tile kt into ring slot
+                uint32_t a_off = a_off_, w_off = w_off_;
+                asm volatile("" : "+v"(a_off), "+v"(w_off));
                 char* dst = smem + slot * BUF_H + wave * 1024;
                 const char* ab = (const char*)(Ag + kt * BK);
                 const char* w0 = (const char*)(Wg + kt * BK);
                 const char* w1 = (const char*)(Wg + (int64_t)kHalfRows * p.K + kt * BK);
-                glds16(ab + a_off[0], dst);
-                glds16(ab + a_pl + a_off[1], dst + 8192);
-                glds16(w0 + w_off[0], dst + REG_B);
-                if constexpr (NW == 2) glds16(w0 + w_pl + w_off[1], dst + REG_B + 8192);
-                glds16(w1 + w_off[0], dst + 2 * REG_B);
-                if constexpr (NW == 2) glds16(w1 + w_pl + w_off[1], dst + 2 * REG_B + 8192);
+                glds16(ab + a_off, dst);
+                glds16(ab + a_d2 + a_off, dst + 8192);
+                glds16(w0 + w_off, dst + REG_B);
+                if constexpr (NW == 2) glds16(w0 + w_d2 + w_off, dst + REG_B + 8192);
+                glds16(w1 + w_off, dst + 2 * REG_B);
+                if constexpr (NW == 2) glds16(w1 + w_d2 + w_off, dst + 2 * REG_B + 8192);
             };
             stage_h(0, 0);
             if (nkt > 1) { stage_h(1, 1); wait_vm<GH>(); }
@@ -527,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
                 slot = slot == 2 ? 0 : slot + 1;
             }
             if (wr == 0) __builtin_amdgcn_s_barrier();
-            pp_epilogue<T, APL, EPI, 1>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+            pp_epilogue<TO, OPL, EPI, 1, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
             chained = false;
             if (it + 1 < it_end) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -728,8 +822,12 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) {
-    const int bk2 = (num.terms == 1) ? 128 : 64;         // two K tiles: the DMA ring's buffer parity is fixed across tiles
-    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K <= 0 || a.K % bk2 || a.lda % 8) return hipErrorInvalidValue;
+    const int bk2 = (num.f16 == 2) ? 256 : ((num.terms == 1) ? 128 : 64);     // two K tiles: the DMA ring's buffer parity is fixed across tiles
+    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K <= 0 || a.K % bk2 || a.lda % 16 || !num_valid(num)) return hipErrorInvalidValue;
+    if (num.f16 == 2) {
+        if (!a.wscale) return hipErrorInvalidValue;
+        return launch_e<f8, 1>(a, epilogue, s);
+    }
     if (!num.f16) {
         if (num.terms == 1) return launch_e<bf16, 1>(a, epilogue, s);
         if (num.terms == 3) return launch_e<bf16, 3>(a, epilogue, s);

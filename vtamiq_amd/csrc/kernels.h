@@ -12,14 +12,18 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
 // Operand format of a dense contraction: element type and MFMAs per product.
 //   terms 1: a*w (one 16-bit plane each);  2: (a_hi + a_lo)*w (activation hi/lo planes, single weight plane);
 //   terms 3: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (hi/lo planes for both).  ABI code (include/vtamiq_hip.h): terms | (f16 ? 16 : 0).
+//   f16 == 2: e4m3 bytes on the MX-scaled MFMA (unit block scales), one plane each, terms = 1; ABI code 33.
 struct Num {
-    int f16;      // 0 = bf16 planes, 1 = fp16 planes
+    int f16;      // 0 = bf16 planes, 1 = fp16 planes, 2 = fp8 (e4m3) bytes
     int terms;    // 1 | 2 | 3
     int apl() const { return terms == 1 ? 1 : 2; }     // planes of an activation tensor
     int wpl() const { return terms == 3 ? 2 : 1; }     // planes of a weight tensor
 };
-inline Num num_from_code(int code) { return Num{(code >> 4) & 1, code & 15}; }
-inline bool num_valid(Num n) { return (n.terms == 1 || n.terms == 3 || (n.terms == 2 && n.f16)) && (n.f16 == 0 || n.f16 == 1); }
+inline Num num_from_code(int code) { return Num{(code >> 4) & 3, code & 15}; }
+inline bool num_valid(Num n) {
+    if (n.f16 == 2) return n.terms == 1;
+    return (n.terms == 1 || n.terms == 3 || (n.terms == 2 && n.f16 == 1)) && (n.f16 == 0 || n.f16 == 1);
+}
 
 // GemmArgs::flags, measurement knobs (environment VTQ_GEMM_FLAGS, read once per process)
 enum { GEMM_FLAG_WRAP_ROWS = 1,     // every tile writes the rows of row panel 0: no HBM write stream (timing experiments only)
@@ -48,6 +52,9 @@ struct GemmArgs {
     const int* row_map;                           // EPI_EMBED: output row of x for GEMM row m, or -1
     const int* idx1; const float* table1;         // EPI_EMBED: + table1[idx1[m]]  (position embedding)
     const int* idx2; const float* table2;         // EPI_EMBED: + table2[idx2[m]]  (scale embedding) or nullptr
+    // fp8 operands only: acc is de-scaled by wscale[n] * ascale_inv before the bias (per-output-channel weight scale, static
+    // activation scale); a GELU output is written as e4m3(value * out_scale); a BIAS output as fp16 hi/lo planes
+    const float* wscale; float ascale_inv; float out_scale;
     const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
     int flags;                                    // set by launch_gemm: GEMM_FLAG_*
 };
@@ -57,12 +64,15 @@ hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
 // per-workgroup lists; entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half
 std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
 
-// fp32 -> 16-bit planes (f16: 0 = bf16, 1 = fp16; planes: 1 = single, 2 = hi + lo with lo `plane` elements behind hi)
-hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s);
+// fp32 -> 16-bit planes (f16: 0 = bf16, 1 = fp16; planes: 1 = single, 2 = hi + lo with lo `plane` elements behind hi), or
+// f16 == 2: e4m3 bytes of value * scale
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s, float scale = 1.0f);
+// fp8 weights: W[N][K] fp32 -> e4m3 rows with a per-row power-of-two scale; inv_scale[n] = 1 / scale
+hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s);
 
 // nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> 16-bit planes [rows_pad, K], rows >= nimg*B*N zero-filled
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16,
-                               int planes, hipStream_t s);
+                               int planes, hipStream_t s, float scale = 1.0f);
 
 // per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1);
 // positions outside [0, 1) are clamped into the table and flagged in *err (bit 0)
@@ -74,11 +84,12 @@ hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, con
                          int T, int H, hipStream_t s);
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int f16, int planes, hipStream_t s);
+                            int f16, int planes, hipStream_t s, float scale = 1.0f);
 
 // num.terms: 1 = single planes, 3 = hi/lo planes for Q, K, V and P (the 2-term form is not offered: DESIGN.md section 2)
+// out8_scale > 0: the output is written as e4m3 bytes of value * out8_scale ([rows][H] bytes) instead of planes (fp8 mode)
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            Num num, hipStream_t s);
+                            Num num, hipStream_t s, float out8_scale = 0.0f);
 
 // zero the rows of the residual stream that belong to no token: per-sequence pads, per-part tails, and everything up to rows_total
 hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s);
