@@ -24,9 +24,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6        # dense bf16 MFMA: 256 CU x 4096 flop/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
 # MFMAs per product of the linear layers (the dominant kernel is a linear layer): vtamiq_amd/_lib.py MFMA_TERMS
-MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0, "fp16": 1.0, "fp16x2": 2.0, "fp16x3": 3.0}
+# fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents (its cap is 2x the bf16 roofline)
+MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0, "fp16": 1.0, "fp16x2": 2.0, "fp16x3": 3.0, "fp8": 0.5}
 HEADLINE = "fp16x3"          # default `value` mode; OTHER_MODES are timed beside it
-OTHER_MODES = ("fp16x2", "fp16")
+OTHER_MODES = ("fp16x2", "fp16", "fp8")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -285,7 +286,8 @@ def main():
         "metric": "image-pairs/sec ViT-B/16 P=500 patches, 1->8 MI355X; % bf16 MFMA roofline",
         "value": pairs_per_s, "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if a.precision.startswith("fp16") else "bf16", "data": "synthetic", "rccl_ranks": rccl_ranks,
+        "dtype": "f16" if a.precision.startswith("fp16") else ("e4m3" if a.precision == "fp8" else "bf16"), "data": "synthetic",
+        "rccl_ranks": rccl_ranks,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
                                f"{N} patches of 16x16x3, random-init seeded weights",
                    "global_batch": global_batch, "patches": N, "seq_len": S, "parallelism": f"dp{world}",
@@ -295,7 +297,11 @@ def main():
                                     "MFMAs per product (scores at the fp32 reference's own noise floor); fp16x2 = activations split, "
                                     "weights single fp16 in the linear layers, 2 MFMAs per product (attention stays 3-term); fp16 / "
                                     "bf16 = 1 MFMA per product (throughput modes, outside the 1e-3 parity tolerance, never claimed as "
-                                    "parity).  A k-MFMA mode can reach at most 1/k of the MFMA roofline (roofline.mode_cap)"},
+                                    "parity).  fp8 = BASELINE configs[4]: e4m3 weights (per-output-channel scales) and e4m3 activations (static "
+                                    "scales) on the MX-scaled MFMA at twice the 16-bit rate, single-fp16 attention; a different MODEL "
+                                    "(3 mantissa bits), checked against its own fake-quant oracle, tens of percent from the fp32 scores "
+                                    "on random-init weights.  A k-MFMA mode can reach at most 1/k of the MFMA roofline "
+                                    "(roofline.mode_cap)"},
         # executed flops: the last layer runs Q/attention/out-proj/MLP for the CLS row only (legal: only token 0 is consumed)
         "forward_mfma_frac": mfma_frac(pairs_per_s),
         "flops_per_pair": f_pair, "flops_per_pair_executed": f_exec,
@@ -309,7 +315,8 @@ def main():
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
         traffic, src = fc1_traffic(a.precision, B)
         mpp = MFMA_PER_PRODUCT[a.precision]
-        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{'f16' if a.precision.startswith('fp16') else 'bf16'}, {int(mpp)}, GELU> (fc1 of every full layer)",
+        elt = "f16" if a.precision.startswith("fp16") else ("f8" if a.precision == "fp8" else "bf16")
+        return {"bound": "mfma", "kernel": f"gemm_pp2_kernel<{elt}, {max(1, int(mpp))}, GELU> (fc1 of every full layer)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": traffic * full_layers / per_step if traffic else None, "traffic_source": src,
                 # the numerics ceiling: bf16x3 issues 3 bf16 MFMAs per algorithmic product
@@ -365,6 +372,9 @@ def main():
         out["parity_vs_cpu_oracle"] = {a.precision: perr(q)}
         for other, q2 in q_other.items():
             out["parity_vs_cpu_oracle"][other] = perr(q2)
+        if "fp8" in out["parity_vs_cpu_oracle"]:
+            out["parity_vs_cpu_oracle"]["fp8"]["note"] = ("distance of the fp8 MODEL to the fp32 reference, reported only: its parity "
+                                                          "statement is tests/test_gpu_fp8.py against oracle/fp8_oracle.py")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np)
         print(json.dumps(out), flush=True)
