@@ -8,7 +8,7 @@ from vtamiq_amd import VTAMIQ, synth, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--patches", type=int, default=500)
 ap.add_argument("--refdefault", action="store_true")
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16"])
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16", "fp8"])
 a = ap.parse_args()
 for prec in a.precision:
     m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True),

@@ -1,19 +1,29 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): collects the rocprofv3 passes behind profiles/*.txt into gpurun_out/prof_<name>/.
-# Counters are collected in their own passes (--pmc with --kernel-trace only), as the MI355X guide prescribes.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -o f -- python3 $R/tools/gemm_bench.py --only fc1 --rounds 1 > $O/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -o w -- python3 $R/tools/gemm_bench.py --only fc1 --rounds 1 > $O/prof_write.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/prof_gemm_pmc -o g -- python3 $R/tools/gemm_bench.py --only fc1 --rounds 1 > $O/prof_gemm_pmc.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/prof_attn_pmc -o a -- python3 $R/tools/attn_bench.py > $O/prof_attn_pmc.log 2>&1
+# Runs on the GPU box (gpurun -- bash tools/collect_profiles.sh): the rocprofv3 passes and runs behind profiles/r02_*.
+# Counters are collected in their own passes (--pmc with --kernel-trace only), as the MI355X guide prescribes; the program
+# itself follows `--` (no env / bash -c hop).  Raw output under gpurun_out/r02p/; tools/make_profiles.py (run in the repo
+# afterwards) writes the summaries kept under profiles/.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O
 cd $R
-for d in stats; do python3 tools/summarize_prof.py stats $O/prof_$d > $O/sum_stats.txt 2>&1; done
-python3 tools/summarize_prof.py pmc $O/prof_fetch gemm > $O/sum_fetch.txt 2>&1
-python3 tools/summarize_prof.py pmc $O/prof_write gemm > $O/sum_write.txt 2>&1
-python3 tools/summarize_prof.py pmc $O/prof_gemm_pmc gemm > $O/sum_gemm_pmc.txt 2>&1
-python3 tools/summarize_prof.py pmc $O/prof_attn_pmc attention > $O/sum_attn_pmc.txt 2>&1
-grep -h "^{\"metric\"" $O/prof_stats.log | tail -1 > $O/bench_line_profiled.json
-rm -rf $O/prof_stats/*trace* 2>/dev/null
+python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_profiled.json 2> $O/stats.err
+G="python3 $R/tools/gemm_bench.py --only fc1 --rounds 1 --fmt fp16x3 fp16x2 fp16 bf16x3 fp8"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- $G > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $G > $O/write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/gemm_pmc -o g -- $G > $O/gemm_pmc.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/gemm_pmc2 -o g -- $G > $O/gemm_pmc2.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/attn_pmc -o a -- python3 $R/tools/attn_bench.py > $O/attn_pmc.log 2>&1
+cd $R
+python3 tools/summarize_prof.py stats $O/stats > $O/sum_stats.txt 2>&1
+for p in fetch write gemm_pmc gemm_pmc2; do python3 tools/summarize_prof.py pmc $O/$p gemm > $O/sum_$p.txt 2>&1; done
+python3 tools/summarize_prof.py pmc $O/attn_pmc attention > $O/sum_attn_pmc.txt 2>&1
+rm -rf $O/stats/*trace* $O/*/*/*kernel_trace* 2>/dev/null
+python3 tools/attn_bench.py > $O/attn_bench.txt 2>&1
+python3 tools/gemm_bench.py --fmt fp16x3 fp16x2 fp16 bf16x3 bf16 fp8 > $O/gemm_bench.txt 2>&1
+python3 tools/golden_errors.py > $O/golden_errors.txt 2>&1
+python3 tools/class_profile.py > $O/class_profile.txt 2>&1
+python3 tools/run_config.py --variant ViT-L16 --batch 16 --patches 1024 --scales 3 > $O/config3_vitl.txt 2>&1
+python3 tools/run_config.py --variant ViT-B16 --batch 16 --patches 512 --scales 5 --refdefault > $O/refdefault.txt 2>&1
+python3 tools/run_config.py --variant ViT-B16 --batch 4 --patches 2500 --scales 1 > $O/n2500.txt 2>&1
 ls $O

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.helpers import E2E_CASES, gate_error, load_case, rel_err, split_inputs
 from vtamiq_amd import VTAMIQ
-MODES = ("fp16x3", "fp16x2", "bf16x3", "fp16", "bf16")
+MODES = ("fp16x3", "fp16x2", "bf16x3", "fp16", "bf16", "fp8")       # fp8: a different model (oracle/fp8_oracle.py), distance reported only
 print("# |q - q_ref| / |q_ref| against the goldens captured from the imported reference (fp32 CPU); min|q_ref|/rms shows how close to")
 print("# zero the smallest score of the case is.  columns per mode: raw max over all scores | raw max over |q_ref| >= 0.1 rms | max |d| / rms | gate")
 worst = {m: 0.0 for m in MODES}

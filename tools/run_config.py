@@ -15,7 +15,7 @@ a = ap.parse_args()
 kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales))
 if a.refdefault:
     kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales), ca_reduction=16)
-for prec in ("fp16x3", "fp16x2", "fp16", "bf16"):
+for prec in ("fp16x3", "fp16x2", "fp16", "bf16", "fp8"):
     m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
     spec = m.spec
     sd = synth.make_state_dict(spec, 0)

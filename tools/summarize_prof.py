@@ -2,9 +2,31 @@
 """Turn rocprofv3 CSV output (kernel_stats / counter_collection) into the small text summaries kept under profiles/."""
 import collections, csv, glob, re, sys
 
+def demangle(n):
+    """_ZN3vtq12_GLOBAL__N_1<len><name>I<template args>E... -> name<args> for the argument kinds these kernels use
+    (llvm-cxxfilt in this ROCm does not know DF16_ = _Float16, so rocprofv3 prints such names mangled)."""
+    m = re.match(r"_ZN3vtq12_GLOBAL__N_1(\d+)", n)
+    if not m:
+        return n
+    ln = int(m.group(1)); i = m.end(); name = n[i:i + ln]; i += ln
+    args = []
+    if i < len(n) and n[i] == "I":
+        i += 1
+        while i < len(n) and n[i] != "E":
+            if n.startswith("DF16_", i): args.append("f16"); i += 5
+            elif n.startswith("DF16b", i): args.append("bf16"); i += 5
+            elif n.startswith("NS_2f8E", i): args.append("f8"); i += 7
+            elif n[i] == "L":
+                j = n.index("E", i); v = n[i + 2:j]; args.append(v.replace("n", "-")); i = j + 1
+            else: args.append("?"); break
+    return f"{name}<{', '.join(args)}>" if args else name
+
+
 def short(n):
+    n = demangle(n)
     n = re.sub(r"void vtq::\(anonymous namespace\)::", "", n)
     n = re.sub(r"vtq::\(anonymous namespace\)::", "", n)
+    n = n.replace("<bool _Accum, int, ELi, E>", "<bf16, .., ..> (name garbled by rocprofv3)").replace("<bool _Accum, int, E>", "<bf16, ..> (name garbled by rocprofv3)")
     return re.sub(r"\(.*", "", n)[:64]
 
 def stats(d):
