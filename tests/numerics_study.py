@@ -168,6 +168,8 @@ SCHEMES = [
     ("h3, last layer's qkv/qk/pv h1", scheme("h3", qkv_at_11="h1", qk_at_11="h1", pv_at_11="h1")),
     ("h3, linears h2a (weights single fp16)", scheme("h3", patch="h2a", qkv="h2a", out="h2a", fc1="h2a", fc2="h2a")),
     ("h3, patch h1 + pv h2w + qk h2a", scheme("h3", patch="h1", pv="h2w", qk="h2a")),
+    ("h3, out + fc2 h2a (weights single fp16 in the two residual-writing linears)", scheme("h3", out="h2a", fc2="h2a")),
+    ("h3, out + fc2 + patch h2a", scheme("h3", out="h2a", fc2="h2a", patch="h2a")),
 ]
 
 

@@ -149,8 +149,8 @@ write("r02_attention_pmc.txt", "\n".join(at))
 write("r02_gemm_bench.txt", "# python3 tools/gemm_bench.py --fmt fp16x3 fp16x2 fp16 bf16x3 bf16 fp8   (encoder GEMM shapes at B=32; median of 7 rounds x 5 launches)\n"
       + clean("r02p/gemm_bench.txt"))
 write("r02_gemm_ablation.txt", "# python3 tools/gemm_bench.py under VTQ_GEMM_FLAGS (kernels.h): 0 = shipped (static per-workgroup tile lists, DMA ring chained across\n"
-      "# tiles), 4 = dynamic tile counter (atomic fetch per tile), 2 = no cross-tile chaining, 8 = epilogue skipped (values wrong by design: the\n"
-      "# epilogue's share of the launch), 12 = 8 + 4.  Same box, same process order.\n" + clean("r02c/gemm_ab.txt"))
+      "# tiles), 4 = one workgroup per tile in hardware dispatch order (the round-1 launch form, no cross-tile state), 8 = epilogue skipped (values\n"
+      "# wrong by design: the epilogue's share of the launch), 12 = 8 + 4.  Same box, two passes over the flag list.\n" + clean("r02c/gemm_ab.txt"))
 write("r02_class_profile.txt", "# python3 tools/class_profile.py   (HIP events on the launch stream around every kernel class; BASELINE configs[1], B=32, N=500)\n"
       + clean("r02p/class_profile.txt"))
 write("r02_golden_errors.txt", "# python3 tools/golden_errors.py   (GPU box)\n" + clean("r02p/golden_errors.txt"))
