@@ -298,3 +298,26 @@ def test_fp8_batch_invariance_and_order():
         q1 = model(tuple(t[1:2] for t in p), tuple(t[1:2] for t in ps), tuple(None if t is None else t[1:2] for t in sc))[0].cpu().numpy()
     assert np.array_equal(qp, q[perm])
     assert np.array_equal(q1, q[1:2])
+
+
+def test_fp8_pairwise_triplets_match_two_calls():
+    """SURVEY 8f-2 in the fp8 mode: the fused (ref, dist1, dist2) entry point reproduces the two model calls bit for bit."""
+    from vtamiq_amd import synth
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=3, num_scales=3))
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+    sd = synth.make_state_dict(m.spec, 31)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    B, N = 4, 60
+    patches, pos, scales = synth.make_inputs(m.spec, B, N, 32, aligned=False)
+    rs = np.random.RandomState(3)
+    d2 = np.clip(patches[:, 0] + 0.2 * rs.randn(*patches[:, 0].shape), -1, 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    pr, pd1, pd2 = t(patches[:, 0]), t(patches[:, 1]), t(d2)
+    qr, qd1 = t(pos[:, 0]), t(pos[:, 1])
+    sr, sd1 = t(scales[:, 0]).float(), t(scales[:, 1]).float()
+    with torch.no_grad():
+        q1 = m((pr, pd1), (qr, qd1), (sr, sd1))[0]
+        q2 = m((pr, pd2), (qr, qd1), (sr, sd1))[0]
+        f1, f2 = m.forward_pairwise((pr, pd1, pd2), (qr, qd1, qd1), (sr, sd1, sd1))
+    assert torch.equal(f1, q1) and torch.equal(f2, q2) and bool(torch.isfinite(f1).all())

@@ -21,16 +21,21 @@ __global__ __launch_bounds__(256) void fold_ca_kernel(const float* __restrict__ 
         if (k == 0) bcat[j] = bc[j];
         return;
     }
+    // eight independent partial sums: the 768-deep dot product is otherwise one chain of dependent load + FMA latencies
+    // (196 us per RCAB at weight load); H % 8 == 0 for every supported width
     const float* wd = Wd + (int64_t)(j - H) * H;
     if (k < H) {
-        float a = 0.f;
-        for (int m = 0; m < H; ++m) a += wd[m] * Wc[(int64_t)m * H + k];
-        Wcat[(int64_t)j * H + k] = a;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < H; m += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = fmaf(wd[m + u], Wc[(int64_t)(m + u) * H + k], a[u]);
+        Wcat[(int64_t)j * H + k] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
-    if (k == 0) {
-        float a = bd[j - H];
-        for (int m = 0; m < H; ++m) a += wd[m] * bc[m];
-        bcat[j] = a;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {           // bias: one wave, lanes stride the sum, butterfly reduce
+        float a = 0.f;
+        for (int m = threadIdx.x; m < H; m += 64) a = fmaf(wd[m], bc[m], a);
+        a = wave_sum(a);
+        if (threadIdx.x == 0) bcat[j] = a + bd[j - H];
     }
 }
 
