@@ -321,6 +321,10 @@ def main():
                 "traffic": traffic * full_layers / per_step if traffic else None, "traffic_source": src,
                 # the numerics ceiling: bf16x3 issues 3 bf16 MFMAs per algorithmic product
                 "mode_cap": 1.0 / mpp, "frac_of_mode_cap": ach / PEAK_BF16_TFLOPS * mpp,
+                # what the matrix pipe sustains on all 256 CUs with register-only back-to-back MFMAs (tools/micro/mfma_peak.hip,
+                # profiles/r02_mfma_peak.txt, two boxes): the chip drops to 1.7-1.9 GHz under that load.  A committed measurement.
+                "matrix_pipe_sustained_tflops_measured": {"f16": [1801, 1923], "bf16": [1930, 2028], "e4m3": [4243, 4500],
+                                                          "source": "profiles/r02_mfma_peak.txt"},
                 "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
                 "flops_per_launch": flops_launch, "note": note}
 
