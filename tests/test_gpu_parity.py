@@ -400,3 +400,19 @@ def test_patch_sample_range_is_checked():
     with pytest.raises(ValueError):
         extract_patches(torch.zeros(1, 24, 24, 3, dtype=torch.uint8, device=DEV), torch.zeros(1, 1, 2, dtype=torch.int32), num_scales=2,
                         scale_ids=torch.zeros(1, 1, dtype=torch.int32))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process (the gpurun box has one)")
+def test_same_process_two_devices():
+    """the library's per-device state (GEMM tile schedules, the > 64 KiB LDS kernel attributes) is keyed by the current
+    device: the same model runs on cuda:0 and then on cuda:1 of one process and gives identical scores."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    qs = []
+    for dev in ("cuda:0", "cuda:1"):
+        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=MAIN)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m = m.to(dev).eval()
+        p, ps, sc = split_inputs(patches, pos, scales, device=dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            qs.append(m(p, ps, sc)[0].cpu().numpy())
+    assert np.array_equal(qs[0], qs[1]) and gate(qs[0], g["q"], TOL[MAIN])

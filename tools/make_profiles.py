@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds the round-2 evidence files under profiles/ from the raw collections merged back into gpurun_out/ by
 tools/collect_profiles.sh (r02p), tools/collect_profiles2.sh (r02q) and the earlier measurement runs of this round
-(r02c gemm ablation, r02d CU-count sweep, r02e column-group sweep, r02f clock evidence, r02i fp8 stage parity).
+(tools/runs/: r02c gemm ablation, r02d CU-count sweep, r02e column-group sweep, r02f clock evidence, r02i fp8 stage parity,
+r02ab same-box comparison with the round-1 tree).
 Run in the repo after the gpurun calls:  python tools/make_profiles.py"""
 import io, json, os, re, subprocess, sys
 from contextlib import redirect_stdout

@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B: round-1 tree (_r01/, built from commit ff1935c) against the current tree: GEMM micro-bench and the bench line
+# setup (in the repo, before the gpurun call): mkdir -p _r01 && git archive ff1935c | tar -x -C _r01 && (cd _r01 && python -m vtamiq_amd.build)   -- _r01/ is git-ignored
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02ab; mkdir -p $O
 for rep in 1 2; do
   cd $R/_r01 && python3 tools/gemm_bench.py --M 32256 --only qkv outproj fc1 fc2 2>&1 | grep -v amdgpu > $O/r01_gemm_$rep.txt
