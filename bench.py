@@ -277,9 +277,12 @@ def main():
     pairs_per_s = global_batch * a.steps / dt
     f_pair = spec.flops_per_pair(N)                      # algorithmic (SURVEY 8d / BASELINE.md)
     pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
-    f_exec = spec.flops_per_pair_executed(N, cls_prune=pruned)
+    # executed flops per pair, per mode: the CLS-only last layer is used by every mode but fp8 (there the CLS row must go through
+    # the same e4m3 GEMMs as every other row, engine.hip run_encoder), which executes the algorithmic count
+    f_exec_of = lambda prec: spec.flops_per_pair_executed(N, cls_prune=pruned and prec != "fp8")
+    f_exec = f_exec_of(a.precision)
     S = spec.seq_len(N)
-    mfma_frac = lambda pps: pps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12)
+    mfma_frac = lambda pps, prec=a.precision: pps / world * f_exec_of(prec) / (PEAK_BF16_TFLOPS * 1e12)
     others = [m for m in OTHER_MODES if m != a.precision]
 
     out = {
@@ -341,7 +344,8 @@ def main():
             dt2, q2, _ = run(model2, a.steps, a.warmup)
             q_other[other] = q2
             out["other_modes"][other] = {"value": global_batch * a.steps / dt2, "unit": "image-pairs/s",
-                                         "forward_mfma_frac": mfma_frac(global_batch * a.steps / dt2),
+                                         "forward_mfma_frac": mfma_frac(global_batch * a.steps / dt2, other),
+                                         "flops_per_pair_executed": f_exec_of(other),
                                          "mfma_per_product_linear": MFMA_PER_PRODUCT[other]}
             del model2
             torch.cuda.empty_cache()
@@ -355,7 +359,7 @@ def main():
             nsteps = max(3, a.steps // 2)
             dtn, _, _ = run(m, nsteps, 2, inp=inp64, gb=Bn)
             ns[prec] = {"value": Bn * nsteps / dtn, "unit": "image-pairs/s", "ms_per_step": dtn / nsteps * 1e3,
-                        "forward_mfma_frac": Bn * nsteps / dtn * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+                        "forward_mfma_frac": Bn * nsteps / dtn * f_exec_of(prec) / (PEAK_BF16_TFLOPS * 1e12),
                         "mode_cap": 1.0 / MFMA_PER_PRODUCT[prec]}
             del m
             torch.cuda.empty_cache()
