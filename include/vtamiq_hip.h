@@ -111,7 +111,9 @@ int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float
 
 /* Input check.  The reference raises (IndexError / device assert) when a position lies outside [0, 1)
  * (transformer.py:417-421); vtq_forward clamps such an index into the table instead of gathering out of bounds and records it.
- * This call synchronises `stream`, returns the flags accumulated since the last call (bit 0: position out of range) and clears them. */
+ * Bit 1: the CLS difference of some pair was not finite -- an operand left its format's range upstream (the fp16 operand modes
+ * carry |v| <= 65504; VTQ_PREC_BF16X3 has the fp32 range), or the inputs / weights held inf / NaN.
+ * This call synchronises `stream`, returns the flags accumulated since the last call and clears them. */
 int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
 
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the

@@ -416,3 +416,27 @@ def test_same_process_two_devices():
         with torch.cuda.device(dev), torch.no_grad():
             qs.append(m(p, ps, sc)[0].cpu().numpy())
     assert np.array_equal(qs[0], qs[1]) and gate(qs[0], g["q"], TOL[MAIN])
+
+
+def test_operand_range_overflow_is_reported():
+    """fp16 operand planes carry |v| <= 65504: a model whose activations exceed that produces inf / NaN, which reach the CLS rows
+    through the softmax; the engine flags a non-finite CLS difference and check_inputs() raises instead of returning NaN silently."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    ok = build(kw, sd, MAIN)
+    with torch.no_grad():
+        ok(p, ps, sc)
+    ok.check_inputs()                                          # a healthy model raises nothing
+    bad_sd = {k: v.copy() for k, v in sd.items()}
+    bad_sd["transformer.encoder.layers.0.attention_norm.weight"][:4] *= 1e7      # LayerNorm outputs of ~1e7 in four channels
+    bad = build(kw, bad_sd, MAIN)
+    with torch.no_grad():
+        q = bad(p, ps, sc)[0]
+    assert not bool(torch.isfinite(q).all())
+    with pytest.raises(FloatingPointError):
+        bad.check_inputs()
+    bad.check_inputs()                                         # the flag is cleared by the check
+    strict = build(kw, bad_sd, MAIN)
+    strict.validate_inputs = True                              # check after every forward (or VTAMIQ_VALIDATE_INPUTS=1)
+    with pytest.raises(FloatingPointError), torch.no_grad():
+        strict(p, ps, sc)

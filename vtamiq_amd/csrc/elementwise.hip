@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int V4>
 __global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ gamma,
-                                                        float* __restrict__ d, int B, SeqMap sm, PlaneOut po) {
+                                                        float* __restrict__ d, int B, SeqMap sm, PlaneOut po, int* __restrict__ err) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x;
     const int pb = blockIdx.x, j = blockIdx.y;           // j-th distorted image (0 for FR pairs; 0,1 for pairwise triplets)
@@ -214,6 +214,9 @@ __global__ __launch_bounds__(64) void final_diff_kernel(const float* __restrict_
         }
         ((float4*)(d + (int64_t)(j * B + pb) * H))[i * 64 + lane] = r;
         plane_store4(po, (int64_t)(j * B + pb), (i * 64 + lane) * 4, r.x, r.y, r.z, r.w);
+        // a non-finite CLS difference: some operand upstream left its format's range (fp16 planes: |v| > 65504) -- any inf / NaN in a
+        // sequence reaches its CLS row through the softmax.  Reported through vtq_input_errors bit 1.
+        if (err && !(isfinite(r.x) && isfinite(r.y) && isfinite(r.z) && isfinite(r.w))) atomicOr(err, 2);
     }
 }
 
@@ -306,9 +309,9 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, void
 }
 
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
-                             SeqMap sm, int H, PlaneOut po, hipStream_t s) {
-    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm, po);
-    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm, po);
+                             SeqMap sm, int H, PlaneOut po, hipStream_t s, int* err) {
+    if (H == 768) hipLaunchKernelGGL(final_diff_kernel<3>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm, po, err);
+    else if (H == 1024) hipLaunchKernelGGL(final_diff_kernel<4>, dim3(B, ndist), dim3(64), 0, s, x, ln_w, ln_b, gamma, d, B, sm, po, err);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -107,7 +107,7 @@ struct vtq_engine {
     int64_t tl_plane = 0, th_plane = 0;
     float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr;   // CLS-only last layer (fp32 rows)
     bool cls_prune = true;
-    int* err_flag = nullptr;             // device word: bit 0 = a position outside [0, 1) was clamped (vtq_input_errors)
+    int* err_flag = nullptr;             // device word (vtq_input_errors): bit 0 = a position outside [0, 1) was clamped, bit 1 = non-finite CLS difference
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
     // profiling
@@ -740,8 +740,8 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         Prof p(e, s, VTQ_K_HEAD);
         float* d = e->hb[0];
         const PlaneOut hp{e->hp[0], e->hp_plane, H, 1, 2, head_first_slope(e)};      // the first head stage's input planes
-        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, hp, s));
-        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s));
+        if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, hp, s, e->err_flag));
+        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s, e->err_flag));
         if (run_head(e, d, HB, q_out, s, true)) return 1;
     }
     return 0;

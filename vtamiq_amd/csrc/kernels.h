@@ -99,7 +99,7 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 
 // d[j*B + b] = gamma * (LN(x[row(b)]) - LN(x[row((j+1)*B + b)])), j < ndist  (final encoder_norm on the CLS rows only; vtamiq.py:104-111)
 hipError_t launch_final_diff(const float* x, const float* ln_w, const float* ln_b, const float* gamma, float* d, int B, int ndist,
-                             SeqMap sm, int H, PlaneOut po, hipStream_t s);
+                             SeqMap sm, int H, PlaneOut po, hipStream_t s, int* err = nullptr);
 
 // one-time RCAB weight fold [Wc ; Wd Wc], bcat = [bc ; Wd bc + bd] (head.hip)
 hipError_t launch_fold_ca(const float* Wc, const float* bc, const float* Wd, const float* bd, float* Wcat, float* bcat, int H, int hid,

@@ -247,7 +247,8 @@ class VTAMIQ(nn.Module):
         self._weights_sig = None
 
     def check_inputs(self):
-        """Synchronise and raise IndexError if any forward since the last check saw a position outside [0, 1)."""
+        """Synchronise and raise IndexError if any forward since the last check saw a position outside [0, 1), FloatingPointError
+        if one produced a non-finite CLS difference (operand range overflow, fp16 modes)."""
         if self._engine is None:
             return
         flags = C.c_int32(0)
@@ -256,6 +257,10 @@ class VTAMIQ(nn.Module):
             _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
         if flags.value & 1:
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
+        if flags.value & 2:
+            raise FloatingPointError(
+                f"non-finite encoder output in precision={self.precision!r}: an activation or weight left the operand format's range "
+                "(fp16 modes: |v| <= 65504) or the inputs held inf / NaN; precision='bf16x3' has the fp32 range")
 
     def _ensure_engine(self, device: torch.device):
         lib = _lib.load()
