@@ -498,8 +498,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         const int tm = tile / ntn, tn = tile - tm * ntn;
         const int64_t m0 = (int64_t)tm * 256 + (kind == 2 ? kHalfRows : 0);
         const int n0 = tn * 256;
-        const T* __restrict__ Ag = (const T*)p.A + m0 * p.lda;
-        const T* __restrict__ Wg = (const T*)p.W + (int64_t)n0 * p.K;
+        const bool wrapl = (p.flags & GEMM_FLAG_WRAP_LOADS) != 0;     // measurement: every tile reads the first two A / W panels (L2 hits)
+        const T* __restrict__ Ag = (const T*)p.A + (wrapl ? (m0 & 511) : m0) * p.lda;
+        const T* __restrict__ Wg = (const T*)p.W + (int64_t)(wrapl ? (n0 & 511) : n0) * p.K;
         // the next entry of this workgroup's list, if the DMA ring may run on into it
         const T* Agn = Ag;
         const T* Wgn = Wg;
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
                 const int dn = sch[it + 1];
                 if ((dn & 3) == 0) {
                     const int tmn = (dn >> 2) / ntn, tnn = (dn >> 2) - tmn * ntn;
-                    Agn = (const T*)p.A + (int64_t)tmn * 256 * p.lda;
-                    Wgn = (const T*)p.W + (int64_t)tnn * 256 * p.K;
+                    Agn = (const T*)p.A + (int64_t)(wrapl ? (tmn & 1) : tmn) * 256 * p.lda;
+                    Wgn = (const T*)p.W + (int64_t)(wrapl ? (tnn & 1) : tnn) * 256 * p.K;
                     has_next = true;
                 }
             }

@@ -30,7 +30,8 @@ enum { GEMM_FLAG_WRAP_ROWS = 1,     // every tile writes the rows of row panel 0
        GEMM_FLAG_NO_CHAIN = 2,      // no DMA chaining across a workgroup's consecutive tiles
        GEMM_FLAG_DYNAMIC = 4,       // one schedule entry per workgroup, as many workgroups as entries (hardware dispatch order
                                     // instead of the persistent lists): the round-1 launch form, for A/B timing
-       GEMM_FLAG_NO_EPILOGUE = 8 }; // skip the epilogue (timing experiments only: output is not written)
+       GEMM_FLAG_NO_EPILOGUE = 8,   // skip the epilogue (timing experiments only: output is not written)
+       GEMM_FLAG_WRAP_LOADS = 16 }; // every tile loads the first two A and W panels: operands always hit L2 (timing experiments only)
 
 // Where the sequences live in the row-major activation buffers: sequence s starts at row s*pitch + (s/per)*gap -- `per`
 // sequences per part-batch, each part-batch padded by `gap` rows to a multiple of 256 (the GEMM tile height).
