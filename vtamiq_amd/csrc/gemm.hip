@@ -1,4 +1,4 @@
-// 16-bit MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues, persistent over a tile schedule.
+// MFMA GEMM for gfx950 (16-bit and e4m3 operands):  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues, persistent over a tile schedule.
 //
 // Replaces every torch.nn.Linear / patch Conv2d on the ViT path of the reference
 // (modules/VisionTransformer/transformer.py:138-140,154-156,169 [QKV/out], :205-206,212-215 [MLP],
@@ -9,7 +9,7 @@
 //   * Both operands are K-contiguous (torch Linear layout) and go global -> LDS by 16-byte LDS-DMA
 //     (global_load_lds_dwordx4).  The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128
 //     fragment reads are removed by XOR-swizzling the 16-byte chunk index on the SOURCE address and on the read
-//     (SQ_LDS_BANK_CONFLICT = 0 measured).
+//     (SQ_LDS_BANK_CONFLICT: 2 % of the launch's cycles for the 16-bit forms, profiles/r02_gemm_fc1_pmc.txt).
 //   * A K tile is four half-tile REGIONS (A rows 0-127 | 128-255, W rows 0-127 | 128-255).  Every wave owns 64 rows
 //     of EACH A half and 32 columns of EACH W half, so an MFMA cluster on quadrant (mh, nh) touches exactly one A
 //     region and one W region and regions are released early -> a DMA ring over two K-tile buffers that runs up to
@@ -27,6 +27,8 @@
 //       2: (a_hi + a_lo)*w                       activation hi/lo planes, weight single plane, BK = 32
 //       3: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo     hi/lo planes for both, BK = 32
 //     into the same fp32 accumulator.
+//     T = f8 (TERMS 1): OCP e4m3 bytes on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, BK = 128; the epilogue first
+//     multiplies the accumulators by wscale[n] * ascale_inv (per-output-channel weight scale, static activation scale).
 //   * PERSISTENT: at most one workgroup per CU walks its own list of tiles (host-built schedule).  The DMA ring runs
 //     straight through a tile boundary: the next tile's first K tile is staged during the current tile's last K tile, so
 //     it lands under the epilogue; only the K tile that would overwrite the epilogue's LDS staging area is deferred to
