@@ -118,6 +118,57 @@ def fc1_traffic(precision, B):
     return None, None
 
 
+def live_fc1_traffic(precision, B, S, timeout_s=150.0):
+    """FETCH_SIZE and WRITE_SIZE of the fc1 GEMM measured NOW, on this box: two child processes (separate --pmc passes, as the
+    MI355X guide prescribes; --kernel-trace only beside them; the program itself after `--`) of
+    `rocprofv3 --pmc <counter> --kernel-trace -- python3 tools/gemm_bench.py --only fc1 --rounds 1 --fmt <precision>`,
+    the same kernel on the same shape as the bench workload's fc1 launch (M = 2 B S padded, N = mlp_dim, K = hidden).
+    Returns (bytes per launch with the gfx950 x2 correction on FETCH_SIZE, description) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import summarize_prof as SP
+    except Exception as e:                                   # pragma: no cover
+        return None, f"tools/summarize_prof.py: {e}"
+    elt = "f16" if precision.startswith("fp16") else ("f8" if precision == "fp8" else "bf16")
+    terms = {"fp16x3": 3, "bf16x3": 3, "fp16x2": 2}.get(precision, 1)
+    want = f"gemm_pp2_kernel<{elt}, {terms}, 1>"
+    M = (2 * B * S + 255) // 256 * 256
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="vtq_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "gemm_bench.py"), "--only", "fc1", "--rounds", "1", "--fmt", precision,
+                   "--M", str(M)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                name = SP.short(row["Kernel_Name"])
+                if row["Counter_Name"] == counter and (name == want or (elt == "bf16" and name.startswith("gemm_pp2_kernel<bf16"))):
+                    tot += float(row["Counter_Value"]); n += 1
+            if n == 0:
+                return None, f"no {want} dispatch in the {counter} pass"
+            vals[counter] = tot / n * 1024.0                    # KiB -> bytes, mean per dispatch
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out"
+    except Exception as e:
+        return None, f"live traffic measurement failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes, --kernel-trace only) on "
+        f"tools/gemm_bench.py --only fc1 --fmt {precision} --M {M}; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
+        f"FETCH {vals['FETCH_SIZE'] / 1e6:.1f} MB counted, WRITE {vals['WRITE_SIZE'] / 1e6:.1f} MB")
+
+
 def effective_cores():
     """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -177,6 +228,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC passes instead of measuring it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are stopped")
     # launcher self-test on CPU (tests/test_bench_launcher.py): gloo ranks + a stub model, no HIP anywhere
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
@@ -385,6 +437,17 @@ def main():
                                                           "statement is tests/test_gpu_fp8.py against oracle/fp8_oracle.py")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np)
+        if "roofline" in out and world == 1 and not a.no_live_traffic:
+            # HBM-side bytes of the dominant kernel measured on THIS box now (the timed regions are over; the GPU is idle)
+            tb, src = live_fc1_traffic(a.precision, B, S)
+            committed = out["roofline"]["traffic"]
+            if tb is not None:
+                full_layers = spec.num_layers - (1 if pruned else 0)
+                out["roofline"]["traffic"] = tb * full_layers / out["roofline"]["launches_per_step"]
+                out["roofline"]["traffic_source"] = src
+                out["roofline"]["traffic_committed_pass"] = committed
+            else:
+                out["roofline"]["traffic_live_error"] = src
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
