@@ -127,6 +127,8 @@ def live_fc1_traffic(precision, B, S, timeout_s=150.0):
     import csv, glob, shutil, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a ROCm profiler: no nested passes"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import summarize_prof as SP
@@ -145,10 +147,21 @@ def live_fc1_traffic(precision, B, S, timeout_s=150.0):
                    sys.executable, os.path.join(ROOT, "tools", "gemm_bench.py"), "--only", "fc1", "--rounds", "1", "--fmt", precision,
                    "--M", str(M)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            # own session: on a timeout the whole group (rocprofv3 and the program under it) is stopped, by exact pgid
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.wait()
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {rc})"
             tot, n = 0.0, 0
             for row in csv.DictReader(open(files[0])):
                 name = SP.short(row["Kernel_Name"])
@@ -157,8 +170,6 @@ def live_fc1_traffic(precision, B, S, timeout_s=150.0):
             if n == 0:
                 return None, f"no {want} dispatch in the {counter} pass"
             vals[counter] = tot / n * 1024.0                    # KiB -> bytes, mean per dispatch
-    except subprocess.TimeoutExpired:
-        return None, "rocprofv3 pass timed out"
     except Exception as e:
         return None, f"live traffic measurement failed: {e}"
     finally:
