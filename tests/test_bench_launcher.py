@@ -60,3 +60,14 @@ def test_under_torchrun_env_no_relaunch():
     p = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "2", "--patches", "4", "--backend", "gloo", "--stub"],
              env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_live_traffic_fails_gracefully_without_a_gpu(monkeypatch):
+    """roofline.traffic is measured by child rocprofv3 passes; where they cannot run (no GPU here, no rocprofv3, or bench.py itself
+    under a profiler) the function reports why and bench.py keeps the committed pass."""
+    import bench
+    tb, why = bench.live_fc1_traffic("fp16x3", 32, 501, timeout_s=120)
+    assert tb is None and isinstance(why, str) and why
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    tb, why = bench.live_fc1_traffic("fp16x3", 32, 501)
+    assert tb is None and "profiler" in why
