@@ -53,8 +53,8 @@ typedef struct vtq_config {
     int32_t mlp_dim;           /* 3072 | 4096                                                         */
     int32_t num_heads;         /* 12 | 16 ; head_dim must be 64                                       */
     int32_t num_layers;        /* kept layers               (transformer.py:342-345)                  */
-    int32_t patch_dim;         /* 3*16*16 = 768                                                       */
-    int32_t pos_grid;          /* 24                        (transformer.py:411)                      */
+    int32_t patch_dim;         /* 3*16*16 = 768 | 3*8*8 = 192 (ViT-B/8, transformer.py:81-85)         */
+    int32_t pos_grid;          /* img_dim / patch: 24 | 48   (transformer.py:411)                     */
     int32_t num_extra_tokens;  /* register tokens           (transformer.py:487-492)                  */
     int32_t num_scales;        /* scale embedding iff > 1   (transformer.py:500)                      */
     int32_t use_layer_scale;   /* ls1/ls2 gamma             (transformer.py:270-271)                  */

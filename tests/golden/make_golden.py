@@ -320,6 +320,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     B16 = "ViT-B16"
+    if len(sys.argv) > 1 and sys.argv[1] == "--vitb8":          # only the ViT-B/8 case (added in round 2; the others are unchanged)
+        run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
+        return
     run_case("c1_b2_n50", dict(vit_config=dict(variant=B16)), B=2, N=50, wseed=1, iseed=11, trace=True)
     run_case("refdefault_b2_n64",
              dict(vit_config=dict(variant=B16, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True,
@@ -334,6 +337,7 @@ def main():
              B=2, N=70, wseed=6, iseed=16)
     run_case("nocalib_b2_n30", dict(vit_config=dict(variant=B16, num_keep_layers=1), calibrate=False, diff_scale=False),
              B=2, N=30, wseed=7, iseed=17)
+    run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
     run_ops()
     run_npz()
     run_plumbing()

@@ -216,11 +216,13 @@ def test_weight_reload_is_seen():
 
 
 @pytest.mark.parametrize("B,N,extra,variant,scales", [(1, 8, 0, "ViT-B16", 0), (5, 77, 0, "ViT-B16", 0), (3, 200, 8, "ViT-B16", 0),
-                                                      (1, 130, 0, "ViT-L16", 3), (7, 56, 3, "ViT-B16", 2), (2, 119, 8, "ViT-B16", 0)])
+                                                      (1, 130, 0, "ViT-L16", 3), (7, 56, 3, "ViT-B16", 2), (2, 119, 8, "ViT-B16", 0),
+                                                      (3, 301, 2, "ViT-B8", 3), (1, 17, 0, "ViT-B8", 0)])
 @pytest.mark.parametrize("precision", ["fp16x3", "fp16x2"])
 def test_ragged_shapes_against_oracle(B, N, extra, variant, scales, precision):
     """Edge shapes: B = 1 / odd B, S = N + T hitting 9 / 78 / 209 / 128 exactly, register tokens, 2- and 3-scale embeddings,
-    ViT-L; oracle on the host as the checker."""
+    ViT-L, ViT-B/8 (8x8 patches: a 192-wide patch embedding padded to the GEMM's K tile, 48 x 48 position grid); oracle on the host
+    as the checker."""
     kw = dict(vit_config=dict(variant=variant, num_keep_layers=2, num_extra_tokens=extra, num_scales=scales, use_layer_scale=bool(extra)),
               num_rgs=2, num_rcabs=2, ca_reduction=16)
     m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)

@@ -182,7 +182,7 @@ def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     h = C.c_void_p()
     assert create(None, C.byref(h)) != 0 and b"null" in lib.vtq_last_error()
     for field, bad, text in [("hidden_size", 512, b"hidden_size"), ("num_heads", 8, b"head_dim"), ("mlp_dim", 1000, b"mlp_dim"),
-                             ("patch_dim", 192, b"patch_dim"), ("num_layers", 0, b"topology"), ("ca_hidden", 3, b"DiffNet"),
+                             ("patch_dim", 300, b"patch_dim"), ("num_layers", 0, b"topology"), ("ca_hidden", 3, b"DiffNet"),
                              ("precision", 7, b"precision")]:
         cfg = Cfg(**{**good, field: bad})
         assert create(C.byref(cfg), C.byref(h)) != 0, field

@@ -36,10 +36,25 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     }
 }
 
+// rows of K floats -> rows of Kp >= K elements, zero beyond K (a weight whose K is padded to the GEMM's K-tile: ViT-B/8's 192-wide
+// patch embedding)
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void split_rows_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t plane, int rows,
+                                                             int K4, int Kp4, float scale) {
+    const int64_t total = (int64_t)rows * Kp4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Kp4;
+        const int c4 = (int)(i - r * Kp4);
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < K4) v = ((const float4*)src)[r * K4 + c4];
+        store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w, scale);
+    }
+}
+
 // fp8 weights: one wave per row of W[N][K]: s = the largest power of two with max|row| * s <= 448 (1 for an all-zero row),
 // dst = e4m3(W * s), inv_scale[n] = 1 / s   (per-output-channel scale; oracle/fp8_oracle.py quant_rows)
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst,
-                                                             float* __restrict__ inv_scale, int N, int K) {
+                                                             float* __restrict__ inv_scale, int N, int K, int Kp) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -55,9 +70,10 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __rest
     if (mx > 0.f) s = exp2f(floorf(log2f(448.0f / mx)));
     if (mx * s > 448.0f) s *= 0.5f;                       // log2f rounding next to an exact power of two, either side
     else if (mx > 0.f && mx * s * 2.0f <= 448.0f) s *= 2.0f;
-    for (int i = lane; i < K / 4; i += 64) {
-        const float4 v = row[i];
-        ((uint32_t*)(dst + (int64_t)n * K))[i] = pack_fp8x4(v.x * s, v.y * s, v.z * s, v.w * s);
+    for (int i = lane; i < Kp / 4; i += 64) {            // destination rows are Kp >= K bytes, zero beyond K
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < K / 4) v = row[i];
+        ((uint32_t*)(dst + (int64_t)n * Kp))[i] = pack_fp8x4(v.x * s, v.y * s, v.z * s, v.w * s);
     }
     if (lane == 0) inv_scale[n] = 1.0f / s;
 }
@@ -67,13 +83,13 @@ struct ImgPtrs { const float* p[3]; };
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, T* __restrict__ dst, int64_t plane, int BN, int K4,
-                                                           int64_t total4, float scale) {
+                                                           int Kp4, int64_t total4, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / K4;
-        const int c4 = (int)(i - row * K4);
+        const int64_t row = i / Kp4;                    // destination rows are Kp4 >= K4 quads wide, zero beyond K4
+        const int c4 = (int)(i - row * Kp4);
         const int img = (int)(row / BN);
         float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (img < nimg) {
+        if (img < nimg && c4 < K4) {
             const float* sp = img == 0 ? src.p[0] : (img == 1 ? src.p[1] : src.p[2]);
             v = ((const float4*)sp)[(row - (int64_t)img * BN) * K4 + c4];
         }
@@ -238,9 +254,21 @@ inline int grid_for(int64_t work, int block) {
         else return hipErrorInvalidValue;                       \
     } while (0)
 
-hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s) {
-    if (K % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, src, (uint8_t*)dst, inv_scale, N, K);
+hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s, int Kp) {
+    if (Kp == 0) Kp = K;
+    if (K % 4 || Kp % 4 || Kp < K) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, src, (uint8_t*)dst, inv_scale, N, K, Kp);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_rows_pad(const float* src, void* dst, int64_t plane, int rows, int K, int Kp, int f16_, int planes, hipStream_t s) {
+    if (K % 4 || Kp % 4 || Kp < K) return hipErrorInvalidValue;
+    const int K4 = K / 4, Kp4 = Kp / 4;
+    const int64_t total = (int64_t)rows * Kp4;
+#define VTQ_CALL(TT, NP) \
+    hipLaunchKernelGGL((split_rows_pad_kernel<TT, NP>), dim3(grid_for(total, 256)), dim3(256), 0, s, src, (TT*)dst, plane, rows, K4, Kp4, 1.0f)
+    VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
+#undef VTQ_CALL
     return hipGetLastError();
 }
 
@@ -254,12 +282,14 @@ hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t nume
 }
 
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16_,
-                               int planes, hipStream_t s, float scale) {
-    const int K4 = K / 4;
-    const int64_t total4 = (int64_t)rows_pad * K4;
+                               int planes, hipStream_t s, float scale, int Kp) {
+    if (Kp == 0) Kp = K;
+    if (K % 4 || Kp % 4 || Kp < K) return hipErrorInvalidValue;
+    const int K4 = K / 4, Kp4 = Kp / 4;
+    const int64_t total4 = (int64_t)rows_pad * Kp4;
     ImgPtrs ip{{imgs[0], imgs[1], nimg > 2 ? imgs[2] : nullptr}};
 #define VTQ_CALL(TT, NP) \
-    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, total4, scale)
+    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, Kp4, total4, scale)
     VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     return hipGetLastError();

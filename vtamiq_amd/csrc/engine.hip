@@ -53,6 +53,7 @@ struct Slot {
     int64_t plane = 0;        // elements between hi and lo plane
     float* scale = nullptr;   // fp8 mode: destination of the rows' inverse scales
     int64_t K = 0;            // row length of a split tensor
+    int64_t Kp = 0;           // row pitch of its packed planes (> K: zero-padded to the GEMM's K tile; 0 = K)
     bool loaded = false;
 };
 
@@ -77,6 +78,7 @@ struct vtq_engine {
     int dbg_stop = -1;                 // tests: leave the encoder after stage layer * 7 + k (vtq_debug_stop_after), -1 = never
     bool fp8 = false;                  // linear layers on e4m3 operands (MX-scaled MFMA, unit block scales): VTQ_PREC_FP8
     float* spatch = nullptr;           //   inverse weight scales of the patch embedding
+    int64_t PDp = 0;                   // patch_dim rounded up to the GEMM's K granule (row pitch of the packed patches / weight)
     int H = 0, Mdim = 0, T = 0;
     std::vector<void*> allocs;
     std::unordered_map<std::string, Slot> slots;
@@ -134,8 +136,9 @@ int add_f32(vtq_engine* e, const std::string& name, float** p, int64_t numel) {
 
 // planes (or e4m3 rows) for a [rows_total, K] weight; sub-slot `name` covers rows [row0, row0 + rows)
 int add_split(vtq_engine* e, const std::string& name, void* base, int64_t plane, int64_t row0, int64_t rows, int64_t K,
-              float* scale_base = nullptr) {
-    Slot s; s.dst = (char*)base + row0 * K * (e->fp8 ? 1 : 2); s.numel = rows * K; s.split = true; s.plane = plane; s.K = K;
+              float* scale_base = nullptr, int64_t Kp = 0) {
+    if (Kp == 0) Kp = K;
+    Slot s; s.dst = (char*)base + row0 * Kp * (e->fp8 ? 1 : 2); s.numel = rows * K; s.split = true; s.plane = plane; s.K = K; s.Kp = Kp;
     s.scale = scale_base ? scale_base + row0 : nullptr;
     e->slots[name] = s;
     return 0;
@@ -152,9 +155,11 @@ int build(vtq_engine* e) {
     const std::string emb = "transformer.embeddings.";
     if (add_f32(e, emb + "cls_token", &e->cls, H)) return 1;
     if (c.num_extra_tokens > 0 && add_f32(e, emb + "extra_tokens", &e->extra, (int64_t)c.num_extra_tokens * H)) return 1;
-    if (alloc_planes(e, &e->wpatch, &e->ppatch, H * PD)) return 1;
+    // the patch-embedding GEMM runs on K padded to 256 (two K tiles of every operand format): 768 as is, ViT-B/8's 192 -> 256
+    e->PDp = round_up(PD, 256);
+    if (alloc_planes(e, &e->wpatch, &e->ppatch, H * e->PDp)) return 1;
     if (e->fp8 && dev_alloc(e, (void**)&e->spatch, H * sizeof(float))) return 1;
-    add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD, e->spatch);
+    add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD, e->spatch, e->PDp);
     if (add_f32(e, emb + "patch_embeddings.bias", &e->bpatch, H)) return 1;
     if (add_f32(e, emb + "positional_embeddings.positional_embeddings", &e->pos_table, ((int64_t)c.pos_grid * c.pos_grid + 1) * H))
         return 1;
@@ -572,7 +577,7 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     if (c.num_heads <= 0 || c.hidden_size / c.num_heads != 64 || c.hidden_size % c.num_heads)
         return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
     if (c.mlp_dim % 256 || c.mlp_dim <= 0) return fail("mlp_dim %d must be a positive multiple of 256", c.mlp_dim);
-    if (c.patch_dim != 768) return fail("patch_dim %d unsupported (3*16*16 only)", c.patch_dim);
+    if (c.patch_dim != 768 && c.patch_dim != 192) return fail("patch_dim %d unsupported (3*16*16 or 3*8*8)", c.patch_dim);
     if (c.num_layers < 1 || c.pos_grid < 1 || c.num_extra_tokens < 0) return fail("bad topology");
     if (c.calibrate && (c.num_rgs < 1 || c.num_rcabs < 1 || c.ca_hidden < 4 || c.ca_hidden % 4 || c.ca_hidden > 256))
         return fail("bad DiffNet topology (rgs %d, rcabs %d, ca_hidden %d)", c.num_rgs, c.num_rcabs, c.ca_hidden);
@@ -624,7 +629,9 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         if (it == e->slots.end()) return fail("vtq_load_weights: unexpected tensor '%s'", d.name);
         Slot& sl = it->second;
         if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
-        if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(d.data, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s));
+        if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(d.data, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s, (int)sl.Kp));
+        else if (sl.split && sl.Kp != sl.K)
+            HIP_TRY(launch_split_rows_pad(d.data, sl.dst, sl.plane, (int)(sl.numel / sl.K), (int)sl.K, (int)sl.Kp, e->f16, e->wpl, s));
         else if (sl.split) HIP_TRY(launch_split(d.data, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
         else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
@@ -707,8 +714,8 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
-        if (e->fp8) HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, 2, 1, s, kSPatch));
-        else HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s));
+        if (e->fp8) HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, 2, 1, s, kSPatch, (int)e->PDp));
+        else HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s, 1.0f, (int)e->PDp));
         HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
                                    c.pos_grid, c.num_scales, e->err_flag, s));
         HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
@@ -717,9 +724,9 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     {
         Prof p(e, s, VTQ_K_PATCH);
         GemmArgs a{};
-        a.A = e->big; a.a_plane = e->big_plane; a.lda = c.patch_dim;
+        a.A = e->big; a.a_plane = e->big_plane; a.lda = (int)e->PDp;
         a.W = e->wpatch; a.w_plane = e->ppatch;
-        a.M = (int)g.P_pad; a.N = H; a.K = c.patch_dim;
+        a.M = (int)g.P_pad; a.N = H; a.K = (int)e->PDp;
         a.bias = e->bpatch; a.x = e->x;
         a.row_map = e->row_map; a.idx1 = e->pidx; a.table1 = e->pos_table;
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;

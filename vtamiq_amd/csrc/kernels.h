@@ -69,11 +69,13 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
 // f16 == 2: e4m3 bytes of value * scale
 hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s, float scale = 1.0f);
 // fp8 weights: W[N][K] fp32 -> e4m3 rows with a per-row power-of-two scale; inv_scale[n] = 1 / scale
-hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s);
+hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s, int Kp = 0);
+// rows of K floats -> planes with row pitch Kp >= K, zero beyond K
+hipError_t launch_split_rows_pad(const float* src, void* dst, int64_t plane, int rows, int K, int Kp, int f16, int planes, hipStream_t s);
 
 // nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> 16-bit planes [rows_pad, K], rows >= nimg*B*N zero-filled
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16,
-                               int planes, hipStream_t s, float scale = 1.0f);
+                               int planes, hipStream_t s, float scale = 1.0f, int Kp = 0);
 
 // per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1);
 // positions outside [0, 1) are clamped into the table and flagged in *err (bit 0)

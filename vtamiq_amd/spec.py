@@ -213,6 +213,6 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
     if vc:
         import warnings
         warnings.warn(f"VisionTransformerBackbone: unused kwargs {sorted(vc)}")   # backbone.py:35 only warns
-    if spec.patch_size != 16:
-        raise NotImplementedError("only 16x16 patches (ViT-B16 / ViT-L16) are on the accelerated path")
+    if spec.patch_size not in (8, 16):
+        raise NotImplementedError("only 16x16 (ViT-B16 / ViT-L16) and 8x8 (ViT-B8) patches are on the accelerated path")
     return spec
