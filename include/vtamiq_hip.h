@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 2
+#define VTQ_ABI_VERSION 3
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -207,10 +207,11 @@ int  vtq_k_image_normalize(const uint8_t* images, float* out, int32_t NI, int32_
 /* torch.nn.AvgPool2d(2): in [NC, H, W] -> out [NC, H/2, W/2]. */
 int  vtq_k_avgpool2(const float* in, float* out, int32_t NC, int32_t H, int32_t W, void* stream);
 /* levels: HOST array of nlevels (<= 4) DEVICE pointers to [NI, 3, hs[l], ws[l]]; samples DEVICE int32 [NI, N, 2] (row, col at the
- * patch's own scale); scale_ids DEVICE int32 [NI, N] or NULL (all scale 0).  Outputs: patches [NI, N, 3, 16, 16],
- * pos [NI, N, 2], scales [NI, N] (fp32-cast ids, may be NULL). */
+ * patch's own scale); scale_ids DEVICE int32 [NI, N] or NULL (all scale 0); patch_size P = 16 | 8.  Outputs: patches [NI, N, 3, P, P],
+ * pos [NI, N, 2] = clamp((sample + P/2) / (dim - P/2), 0, 1 - 1e-6), scales [NI, N] (fp32-cast ids, may be NULL). */
 int  vtq_k_gather_patches(const float* const* levels, const int32_t* hs, const int32_t* ws, int32_t nlevels, const int32_t* samples,
-                          const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, void* stream);
+                          const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, int32_t patch_size,
+                          void* stream);
 
 /* ---- validation-loop reductions; fp64 like the reference's numpy arrays ------------------------------------ */
 /* average_over_repeats (train.py:398-400): q fp32 [R, N] (repeat-major, as the concatenated passes of do_validation) ->

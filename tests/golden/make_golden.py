@@ -244,14 +244,14 @@ def run_npz():
     print("npz_ingest_tiny:", len(out), "arrays")
 
 
-def run_patches():
+def run_patches(P=16, fname="patches_gather.npz", seed=11):
     """the gather / position / pyramid part of the loader, pinned by the reference's get_iqa_patches driven by a
-    RECORDING sampler (deterministic coordinates; the sampler's RNG is out of scope)."""
+    RECORDING sampler (deterministic coordinates; the sampler's RNG is out of scope).  P = 16 (ViT-B16 / L16) and P = 8 (ViT-B8)."""
     _install_train_stubs()
     from data import patch_sampling as PS
     from oracle.patch_oracle import transform_img
-    rs = np.random.RandomState(11)
-    H, W, P = 160, 208, 16
+    rs = np.random.RandomState(seed)
+    H, W = 160, 208
     imgs = [rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in range(2)]
     imgs[1] = np.clip(imgs[0].astype(np.int32) + rs.randint(-20, 21, size=(H, W, 3)), 0, 255).astype(np.uint8)
 
@@ -276,7 +276,7 @@ def run_patches():
         out[f"{tag}/ncalls"] = np.array(len(rec.calls))
         for i, (h, w, smp) in enumerate(rec.calls):
             out[f"{tag}/call{i}/hw"] = np.array([h, w]); out[f"{tag}/call{i}/samples"] = smp
-    np.savez_compressed(os.path.join(HERE, "patches_gather.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
     print("patches_gather:", {k: v.shape for k, v in out.items() if k.endswith("patches")})
 
 
@@ -322,6 +322,7 @@ def main():
     B16 = "ViT-B16"
     if len(sys.argv) > 1 and sys.argv[1] == "--vitb8":          # only the ViT-B/8 case (added in round 2; the others are unchanged)
         run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
+        run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
         return
     run_case("c1_b2_n50", dict(vit_config=dict(variant=B16)), B=2, N=50, wseed=1, iseed=11, trace=True)
     run_case("refdefault_b2_n64",
@@ -342,6 +343,7 @@ def main():
     run_npz()
     run_plumbing()
     run_patches()
+    run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
     run_validation_metrics()
 
 

@@ -265,19 +265,20 @@ def test_diffnet_head_against_oracle(kw, HB, precision):
     assert abs(err).max() < 2e-5 * max(1.0, abs(ref).max()), (abs(err).max(), abs(ref).max())
 
 
+@pytest.mark.parametrize("P", [16, 8])
 @pytest.mark.parametrize("tag", ["aligned", "unaligned"])
-def test_device_patch_extraction_bit_exact(tag):
+def test_device_patch_extraction_bit_exact(tag, P):
     """uint8 images + coordinates -> (patches, pos, scales) on the GPU, bit-exact against the golden captured
     from the reference's get_iqa_patches (3 scales, flips in the unaligned case) and against the oracle."""
     from tests.test_patch_oracle import load_patch_golden
     from vtamiq_amd.patches import extract_patches
     import numpy as np
-    g, imgs, flips, samples, dims = load_patch_golden(tag)
+    g, imgs, flips, samples, dims = load_patch_golden(tag, P)
     nsc = len(samples)
     smp = np.stack([np.concatenate([samples[s][k].T for s in range(nsc)]) for k in range(2)]).astype(np.int32)      # [2, N, 2]
     sid = np.stack([np.concatenate([np.full(samples[s][k].shape[1], s) for s in range(nsc)]) for k in range(2)]).astype(np.int32)
     fl = torch.tensor([[int(flips[0]), int(flips[1])]] * 2, dtype=torch.int32)
-    patches, pos, scales = extract_patches(torch.from_numpy(np.stack(imgs)).to(DEV), torch.from_numpy(smp), torch.from_numpy(sid), nsc, fl)
+    patches, pos, scales = extract_patches(torch.from_numpy(np.stack(imgs)).to(DEV), torch.from_numpy(smp), torch.from_numpy(sid), nsc, fl, patch_size=P)
     torch.cuda.synchronize()
     assert np.array_equal(patches.cpu().numpy(), g[f"{tag}/patches"])
     assert np.array_equal(pos.cpu().numpy(), g[f"{tag}/pos"])

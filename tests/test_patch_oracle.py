@@ -8,8 +8,11 @@ from oracle import patch_oracle as PO
 from tests.helpers import GOLDEN
 
 
-def load_patch_golden(tag):
-    g = dict(np.load(os.path.join(GOLDEN, "patches_gather.npz")))
+PATCH_GOLDENS = {16: "patches_gather.npz", 8: "patches_gather_p8.npz"}     # patch size -> fixture (ViT-B16 / L16, ViT-B8)
+
+
+def load_patch_golden(tag, P=16):
+    g = dict(np.load(os.path.join(GOLDEN, PATCH_GOLDENS[P])))
     imgs = [g["img0"], g["img1"]]
     flips = tuple(bool(v) for v in g[f"{tag}/flips"])
     ncalls = int(g[f"{tag}/ncalls"])
@@ -21,11 +24,16 @@ def load_patch_golden(tag):
     return g, imgs, flips, samples, dims
 
 
-def test_oracle_matches_reference_get_iqa_patches():
+import pytest
+
+
+@pytest.mark.parametrize("P", [16, 8])
+def test_oracle_matches_reference_get_iqa_patches(P):
     for tag in ("aligned", "unaligned"):
-        g, imgs, flips, samples, dims = load_patch_golden(tag)
+        g, imgs, flips, samples, dims = load_patch_golden(tag, P)
         tens = [PO.transform_img(im, flips[0], flips[1]) for im in imgs]
-        patches, pos, scales = PO.extract_patches(tens, samples)
+        patches, pos, scales = PO.extract_patches(tens, samples, patch_dim=P)
+        assert patches.shape[-2:] == (P, P)
         np.testing.assert_array_equal(patches.numpy(), g[f"{tag}/patches"])
         np.testing.assert_array_equal(pos.numpy(), g[f"{tag}/pos"])
         np.testing.assert_array_equal(scales.numpy(), g[f"{tag}/scales"])

@@ -894,9 +894,11 @@ int vtq_k_avgpool2(const float* in, float* out, int32_t NC, int32_t H, int32_t W
 }
 
 int vtq_k_gather_patches(const float* const* levels, const int32_t* hs, const int32_t* ws, int32_t nlevels, const int32_t* samples,
-                         const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, void* stream) {
+                         const int32_t* scale_ids, float* patches, float* pos, float* scales, int32_t NI, int32_t N, int32_t patch_size,
+                         void* stream) {
     if (!levels || !hs || !ws || !samples || !patches || !pos) return fail("vtq_k_gather_patches: null argument");
-    HIP_TRY(launch_gather_patches(levels, hs, ws, nlevels, samples, scale_ids, patches, pos, scales, NI, N, (hipStream_t)stream));
+    if (patch_size != 16 && patch_size != 8) return fail("vtq_k_gather_patches: patch_size %d (16 or 8)", patch_size);
+    HIP_TRY(launch_gather_patches(levels, hs, ws, nlevels, samples, scale_ids, patches, pos, scales, NI, N, (hipStream_t)stream, patch_size));
     return 0;
 }
 

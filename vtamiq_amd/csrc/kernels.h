@@ -146,7 +146,7 @@ hipError_t launch_image_normalize(const uint8_t* in, float* out, int NI, int H, 
                                   hipStream_t s);
 hipError_t launch_avgpool2(const float* in, float* out, int NC, int H, int W, hipStream_t s);
 hipError_t launch_gather_patches(const float* const* levels, const int* hs, const int* ws, int nlevels, const int* samples,
-                                 const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s);
+                                 const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s, int P = 16);
 
 // ---- validation reductions (metrics.hip) --------------------------------------------------------------------------------
 hipError_t launch_repeat_mean(const float* q, double* out, int R, int N, hipStream_t s);

@@ -48,10 +48,10 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__
 
 struct Levels { const float* p[4]; int h[4]; int w[4]; };
 
-// one workgroup per (patch n, image ni): 256 threads = the 16x16 pixels, loop over the 3 channels
+// one workgroup per (patch n, image ni): P*P threads = the pixels of a PxP patch (P = 16 | 8), loop over the 3 channels
 __global__ __launch_bounds__(256) void gather_patches_kernel(Levels lv, const int* __restrict__ samples, const int* __restrict__ scale_ids,
                                                              float* __restrict__ patches, float* __restrict__ pos, float* __restrict__ scales,
-                                                             int N, int write_scales) {
+                                                             int N, int write_scales, int P) {
     const int n = blockIdx.x, ni = blockIdx.y;
     const int64_t pn = (int64_t)ni * N + n;
     const int sc = scale_ids ? scale_ids[pn] : 0;
@@ -59,14 +59,15 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(Levels lv, const in
     const int h = sc == 0 ? lv.h[0] : (sc == 1 ? lv.h[1] : (sc == 2 ? lv.h[2] : lv.h[3]));
     const int w = sc == 0 ? lv.w[0] : (sc == 1 ? lv.w[1] : (sc == 2 ? lv.w[2] : lv.w[3]));
     const int row = samples[pn * 2], col = samples[pn * 2 + 1];
-    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int PP = P * P, i = threadIdx.x / P, j = threadIdx.x - i * P;
     const float* img = base + (int64_t)ni * 3 * h * w;
-    float* dst = patches + pn * 768;
+    float* dst = patches + pn * 3 * PP;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dst[c * 256 + threadIdx.x] = img[((int64_t)c * h + row + i) * w + col + j];
+    for (int c = 0; c < 3; ++c) dst[c * PP + threadIdx.x] = img[((int64_t)c * h + row + i) * w + col + j];
     if (threadIdx.x < 2) {
-        const float smp = (float)(threadIdx.x == 0 ? row : col) + 8.0f;
-        const float den = (float)((threadIdx.x == 0 ? h : w) - 8);
+        const float half = (float)(P / 2);                       // data/patch_sampling.py:565-568
+        const float smp = (float)(threadIdx.x == 0 ? row : col) + half;
+        const float den = (float)(threadIdx.x == 0 ? h : w) - half;
         pos[pn * 2 + threadIdx.x] = fminf(fmaxf(smp / den, 0.0f), (float)(1.0 - 1e-6));
     }
     if (write_scales && threadIdx.x == 2) scales[pn] = (float)sc;
@@ -91,14 +92,14 @@ hipError_t launch_avgpool2(const float* in, float* out, int NC, int H, int W, hi
 }
 
 hipError_t launch_gather_patches(const float* const* levels, const int* hs, const int* ws, int nlevels, const int* samples,
-                                 const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s) {
-    if (nlevels < 1 || nlevels > 4) return hipErrorInvalidValue;
+                                 const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s, int P) {
+    if (nlevels < 1 || nlevels > 4 || (P != 16 && P != 8)) return hipErrorInvalidValue;
     Levels lv{};
     for (int i = 0; i < 4; ++i) {
         const int k = i < nlevels ? i : nlevels - 1;
         lv.p[i] = levels[k]; lv.h[i] = hs[k]; lv.w[i] = ws[k];
     }
-    hipLaunchKernelGGL(gather_patches_kernel, dim3(N, NI), dim3(256), 0, s, lv, samples, scale_ids, patches, pos, scales, N, scales != nullptr);
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(N, NI), dim3(P * P), 0, s, lv, samples, scale_ids, patches, pos, scales, N, scales != nullptr, P);
     return hipGetLastError();
 }
 

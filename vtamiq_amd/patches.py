@@ -12,11 +12,12 @@ from . import _lib
 
 
 def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: Optional[torch.Tensor] = None, num_scales: int = 1,
-                    flips: Optional[torch.Tensor] = None, mean: Sequence[float] = (0.5, 0.5, 0.5), std: Sequence[float] = (0.5, 0.5, 0.5)
-                    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+                    flips: Optional[torch.Tensor] = None, mean: Sequence[float] = (0.5, 0.5, 0.5), std: Sequence[float] = (0.5, 0.5, 0.5),
+                    patch_size: int = 16) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """images_u8 [NI, H, W, 3] uint8 (cuda); samples [NI, N, 2] int32 (row, col at the patch's own scale);
     scale_ids [NI, N] int32 (required when num_scales > 1, patches of scale s index pyramid level s); flips [NI, 2] int32
-    (hflip, vflip) or None.  Returns patches [NI, N, 3, 16, 16] f32, pos [NI, N, 2] f32, scales [NI, N] f32 or None."""
+    (hflip, vflip) or None; patch_size P = 16 (ViT-B16 / ViT-L16) or 8 (ViT-B8).  Returns patches [NI, N, 3, P, P] f32, pos [NI, N, 2] f32,
+    scales [NI, N] f32 or None."""
     lib = _lib.load()
     dev = images_u8.device
     if dev.type != "cuda":
@@ -31,20 +32,23 @@ def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: O
         raise ValueError("scale_ids are required when num_scales > 1")
     if not 1 <= num_scales <= 4:
         raise ValueError("1 <= num_scales <= 4")
+    P = int(patch_size)
+    if P not in (16, 8):
+        raise ValueError("patch_size must be 16 or 8")
     # Range checks the reference gets for free from numpy fancy-indexing (an out-of-range patch raises IndexError there); the
     # gather kernel itself does not bounds-check.  One small reduction + sync per call, on the loader side of the pipeline.
-    if (H >> (num_scales - 1)) < 16 or (W >> (num_scales - 1)) < 16:
-        raise ValueError(f"pyramid level {num_scales - 1} of a {H}x{W} image is smaller than one 16x16 patch")
+    if (H >> (num_scales - 1)) < P or (W >> (num_scales - 1)) < P:
+        raise ValueError(f"pyramid level {num_scales - 1} of a {H}x{W} image is smaller than one {P}x{P} patch")
     smp = samples.to(torch.int64)
     lvl = scale_ids.to(device=smp.device, dtype=torch.int64) if scale_ids is not None else torch.zeros(smp.shape[:2], dtype=torch.int64, device=smp.device)
     if tuple(lvl.shape) != (NI, N):
         raise ValueError("scale_ids must be int32 [NI, N]")
     if bool(((lvl < 0) | (lvl >= num_scales)).any()):
         raise IndexError("scale_ids outside [0, num_scales)")
-    hmax = torch.tensor([(H >> s) - 16 for s in range(num_scales)], device=smp.device)[lvl]
-    wmax = torch.tensor([(W >> s) - 16 for s in range(num_scales)], device=smp.device)[lvl]
+    hmax = torch.tensor([(H >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
+    wmax = torch.tensor([(W >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
     if bool(((smp[..., 0] < 0) | (smp[..., 0] > hmax) | (smp[..., 1] < 0) | (smp[..., 1] > wmax)).any()):
-        raise IndexError("patch sample outside its pyramid level (row in [0, h-16], col in [0, w-16] required)")
+        raise IndexError(f"patch sample outside its pyramid level (row in [0, h-{P}], col in [0, w-{P}] required)")
     images_u8 = images_u8.contiguous()
     samples = samples.to(device=dev, dtype=torch.int32).contiguous()
     sid = scale_ids.to(device=dev, dtype=torch.int32).contiguous() if scale_ids is not None else None
@@ -61,7 +65,7 @@ def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: O
             nxt = torch.empty(NI, 3, h // 2, w // 2, device=dev, dtype=torch.float32)
             _lib.check(lib.vtq_k_avgpool2(levels[-1].data_ptr(), nxt.data_ptr(), NI * 3, h, w, stream))
             levels.append(nxt)
-        patches = torch.empty(NI, N, 3, 16, 16, device=dev, dtype=torch.float32)
+        patches = torch.empty(NI, N, 3, P, P, device=dev, dtype=torch.float32)
         pos = torch.empty(NI, N, 2, device=dev, dtype=torch.float32)
         scales = torch.empty(NI, N, device=dev, dtype=torch.float32) if num_scales > 1 else None
         ptrs = (C.c_void_p * len(levels))(*[l.data_ptr() for l in levels])
@@ -69,5 +73,5 @@ def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: O
         ws = (C.c_int32 * len(levels))(*[l.shape[3] for l in levels])
         _lib.check(lib.vtq_k_gather_patches(ptrs, hs, ws, len(levels), samples.data_ptr(), sid.data_ptr() if sid is not None else None,
                                             patches.data_ptr(), pos.data_ptr(), scales.data_ptr() if scales is not None else None, NI, N,
-                                            stream))
+                                            P, stream))
     return patches, pos, scales
