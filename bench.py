@@ -118,6 +118,9 @@ def fc1_traffic(precision, B):
     return None, None
 
 
+LIVE_EXTRA = {}      # filled by live_fc1_traffic: counters of the third pass (MFMA-pipe utilisation)
+
+
 def live_fc1_traffic(precision, B, S, timeout_s=150.0):
     """FETCH_SIZE and WRITE_SIZE of the fc1 GEMM measured NOW, on this box: two child processes (separate --pmc passes, as the
     MI355X guide prescribes; --kernel-trace only beside them; the program itself after `--`) of
@@ -141,9 +144,10 @@ def live_fc1_traffic(precision, B, S, timeout_s=150.0):
     vals = {}
     tmp = tempfile.mkdtemp(prefix="vtq_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES")):
+            counter = counters[0]
             d = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+            cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "tools", "gemm_bench.py"), "--only", "fc1", "--rounds", "1", "--fmt", precision,
                    "--M", str(M)]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -161,19 +165,30 @@ def live_fc1_traffic(precision, B, S, timeout_s=150.0):
                 return None, f"rocprofv3 --pmc {counter} pass timed out"
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if rc != 0 or not files:
+                if counter == "GRBM_GUI_ACTIVE":
+                    break                                       # the utilisation pass is optional: keep the traffic
                 return None, f"rocprofv3 --pmc {counter} failed (rc {rc})"
-            tot, n = 0.0, 0
+            tot, n = {c: 0.0 for c in counters}, {c: 0 for c in counters}
             for row in csv.DictReader(open(files[0])):
                 name = SP.short(row["Kernel_Name"])
-                if row["Counter_Name"] == counter and (name == want or (elt == "bf16" and name.startswith("gemm_pp2_kernel<bf16"))):
-                    tot += float(row["Counter_Value"]); n += 1
-            if n == 0:
+                if row["Counter_Name"] in tot and (name == want or (elt == "bf16" and name.startswith("gemm_pp2_kernel<bf16"))):
+                    tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
+            if min(n.values()) == 0:
+                if counter == "GRBM_GUI_ACTIVE":
+                    break
                 return None, f"no {want} dispatch in the {counter} pass"
-            vals[counter] = tot / n * 1024.0                    # KiB -> bytes, mean per dispatch
+            for c in counters:
+                vals[c] = tot[c] / n[c]
+            if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[counter] *= 1024.0                        # KiB -> bytes, mean per dispatch
     except Exception as e:
         return None, f"live traffic measurement failed: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    if "GRBM_GUI_ACTIVE" in vals and vals["GRBM_GUI_ACTIVE"] > 0:
+        # MFMA-pipe busy fraction of the launch: busy SIMD-cycles / (1024 SIMDs x cycles per XCD); GRBM_GUI_ACTIVE is summed over 8 XCDs
+        LIVE_EXTRA["mfma_busy_frac"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)
+        LIVE_EXTRA["cycles_per_xcd"] = vals["GRBM_GUI_ACTIVE"] / 8.0
     return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], (
         "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes, --kernel-trace only) on "
         f"tools/gemm_bench.py --only fc1 --fmt {precision} --M {M}; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
@@ -457,6 +472,12 @@ def main():
                 out["roofline"]["traffic"] = tb * full_layers / out["roofline"]["launches_per_step"]
                 out["roofline"]["traffic_source"] = src
                 out["roofline"]["traffic_committed_pass"] = committed
+                # HBM-side rate of the kernel (L2-miss side bytes, Infinity-Cache hits included) against the 8 TB/s peak
+                out["roofline"]["memory_side_tbps"] = out["roofline"]["traffic"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e12
+                if "mfma_busy_frac" in LIVE_EXTRA:
+                    out["roofline"]["mfma_busy_frac_measured"] = LIVE_EXTRA["mfma_busy_frac"]
+                    out["roofline"]["mfma_busy_note"] = ("rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES on the same kernel in this "
+                                                         "run: busy SIMD-cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)")
             else:
                 out["roofline"]["traffic_live_error"] = src
         print(json.dumps(out), flush=True)
