@@ -158,6 +158,8 @@ class VTAMIQ(nn.Module):
                                          nn.Linear(H // 4, 1))              # vtamiq.py:71-77 (Dropout slots 0 and 3)
         self.return_features = return_features
         precision = precision or os.environ.get("VTAMIQ_PRECISION", DEFAULT_PRECISION)
+        if precision == "fp8w":                 # alias used by the round-1 review for BASELINE configs[4] ("fp8 weights"): same mode
+            precision = "fp8"
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
         self.precision = precision
