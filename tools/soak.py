@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Soak run (GPU box): the bench workload (B = 32, N = 500) N times per mode, every result compared bit for bit with the first --
+a race / uninitialised-memory detector at full size (126 x 12 tiles per GEMM launch, all CUs, chained tile lists)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vtamiq_amd import VTAMIQ, synth
+
+ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=200); ap.add_argument("--modes", nargs="+", default=["fp16x3", "fp16x2", "fp16", "bf16x3", "fp8"])
+a = ap.parse_args()
+bad = 0
+for prec in a.modes:
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", pretrained=False), precision=prec)
+    sd = synth.make_state_dict(m.spec, 0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
+    patches, pos, _ = synth.make_inputs(m.spec, 32, 500, 7)
+    tp, tq = torch.from_numpy(patches).cuda(), torch.from_numpy(pos).cuda()
+    args = ((tp[:, 0].contiguous(), tp[:, 1].contiguous()), (tq[:, 0].contiguous(), tq[:, 1].contiguous()), (None, None))
+    with torch.no_grad():
+        q0 = m(*args)[0].clone()
+        diff = 0
+        for i in range(a.reps):
+            q = m(*args)[0]
+            if not torch.equal(q, q0):
+                diff += 1
+        torch.cuda.synchronize()
+    print(f"{prec}: {a.reps} repeated forwards at B=32, N=500: {diff} differ from the first", flush=True)
+    bad += diff
+    del m; torch.cuda.empty_cache()
+sys.exit(1 if bad else 0)
