@@ -461,3 +461,20 @@ def test_repeated_forwards_are_bitwise_identical(precision):
                 m(other, ps, sc)
             q = m(p, ps, sc)[0]
             assert torch.equal(q, q0), (i, (q - q0).abs().max().item())
+
+
+def test_workspace_regrowth_keeps_results():
+    """The workspace is sized by the high-water mark of (B, N): small -> large -> small -> longer sequences on ONE engine give the
+    scores a fresh engine gives for each call (no stale rows, padding or schedules carried over)."""
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=2))
+    spec = VTAMIQ(**json.loads(json.dumps(kw))).spec
+    sd = synth.make_state_dict(spec, 77)
+    one = build(kw, sd, MAIN)
+    for B, N, seed in [(2, 40, 1), (19, 130, 2), (3, 40, 3), (1, 700, 4), (5, 9, 5)]:
+        patches, pos, sc = synth.make_inputs(spec, B, N, seed)
+        p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+        fresh = build(kw, sd, MAIN)
+        with torch.no_grad():
+            qa, qb = one(p, ps, s3)[0], fresh(p, ps, s3)[0]
+        assert torch.equal(qa, qb), (B, N, (qa - qb).abs().max().item())
+        del fresh
