@@ -438,6 +438,13 @@ def test_operand_range_overflow_is_reported():
     with pytest.raises(FloatingPointError):
         bad.check_inputs()
     bad.check_inputs()                                         # the flag is cleared by the check
+    # the poisoned workspace does not leak into later healthy forwards of the SAME engine (stale rows behind a smaller batch)
+    bad.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    with torch.no_grad():
+        q_small = bad(tuple(t[:1] for t in p), tuple(t[:1] for t in ps), sc)[0]
+        q_ref_small = ok(tuple(t[:1] for t in p), tuple(t[:1] for t in ps), sc)[0]
+    assert torch.equal(q_small, q_ref_small)
+    bad.check_inputs()
     strict = build(kw, bad_sd, MAIN)
     strict.validate_inputs = True                              # check after every forward (or VTAMIQ_VALIDATE_INPUTS=1)
     with pytest.raises(FloatingPointError), torch.no_grad():

@@ -735,6 +735,13 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     }
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
 
+    // The last 64-key tile of the last sequence reads K / V rows up to 63 past M_pad in the QKV layout of `big`.  Masked keys
+    // multiply by probability 0, which only holds for FINITE stale values: a previous forward that overflowed (inf / NaN, see
+    // vtq_input_errors bit 1) with a larger batch would otherwise poison this one's first layer.  From layer 1 on the region
+    // holds this forward's own fc1 output.
+    for (int pl = 0; pl < e->apl; ++pl)
+        HIP_TRY(hipMemsetAsync((char*)e->big + ((size_t)pl * e->big_plane + (size_t)g.M_pad * 3 * H) * 2, 0, (size_t)128 * 3 * H * 2, s));
+
     // ---- encoder (transformer.py:363-378, 275-285) -------------------------------------------------------------
     // the trace tap needs every token row of the last layer; sequences longer than the CLS kernel's LDS score buffer run the
     // full last layer instead (same result)
