@@ -64,7 +64,8 @@ typedef struct vtq_config {
     int32_t num_rcabs;         /* vtamiq.py:35                                                        */
     int32_t ca_hidden;         /* hidden_size / ca_reduction (channel_attention.py:75)                */
     int32_t precision;         /* VTQ_PREC_*                                                          */
-    int32_t reserved[5];
+    int32_t num_adapters;      /* Adapter pairs per layer (transformer.py:260-269); pair 0 is applied   */
+    int32_t reserved[4];
 } vtq_config;
 
 typedef struct vtq_tensor_desc {

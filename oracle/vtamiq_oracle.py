@@ -92,14 +92,26 @@ def mlp(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
     return h @ sd[prefix + "ffn.fc2.weight"].t() + sd[prefix + "ffn.fc2.bias"]
 
 
+def adapter(sd: Dict[str, Tensor], prefix: str, h: Tensor) -> Tensor:
+    """Adapter.forward: h + Linear(gelu(Linear(h))).  transformer.py:177-194 (nn.GELU() = exact erf form)."""
+    a = F.gelu(h @ sd[prefix + "adapter.0.weight"].t() + sd[prefix + "adapter.0.bias"])
+    return h + a @ sd[prefix + "adapter.2.weight"].t() + sd[prefix + "adapter.2.bias"]
+
+
 def encoder_layer(sd: Dict[str, Tensor], spec, i: int, x: Tensor) -> Tensor:
-    """EncoderLayer.forward (pre-LN; DropPath is identity).  transformer.py:275-285."""
+    """EncoderLayer.forward (pre-LN; DropPath is identity).  transformer.py:275-285.
+    With num_adapters > 0 the forward applies adapter pair 0 (backbone.py:54-57: adapter_num defaults to 0)."""
     p = f"transformer.encoder.layers.{i}."
+    ad = getattr(spec, "num_adapters", 0) > 0
     h = attention(sd, p, _layer_norm(x, sd[p + "attention_norm.weight"], sd[p + "attention_norm.bias"]), spec.num_heads)
+    if ad:
+        h = adapter(sd, p + "adapter1.", h)
     if spec.use_layer_scale:
         h = h * sd[p + "ls1.gamma"]
     x = x + h
     h = mlp(sd, p, _layer_norm(x, sd[p + "ffn_norm.weight"], sd[p + "ffn_norm.bias"]))
+    if ad:
+        h = adapter(sd, p + "adapter2.", h)
     if spec.use_layer_scale:
         h = h * sd[p + "ls2.gamma"]
     return x + h

@@ -320,6 +320,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     B16 = "ViT-B16"
+    if len(sys.argv) > 1 and sys.argv[1] == "--adapters":       # only the adapter case (added in round 2; the others are unchanged)
+        run_case("adapters_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, num_adapters=2, use_layer_scale=True, num_extra_tokens=1)),
+                 B=2, N=40, wseed=22, iseed=19)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--vitb8":          # only the ViT-B/8 case (added in round 2; the others are unchanged)
         run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
         run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
@@ -339,6 +343,8 @@ def main():
     run_case("nocalib_b2_n30", dict(vit_config=dict(variant=B16, num_keep_layers=1), calibrate=False, diff_scale=False),
              B=2, N=30, wseed=7, iseed=17)
     run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
+    run_case("adapters_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, num_adapters=2, use_layer_scale=True, num_extra_tokens=1)),
+             B=2, N=40, wseed=22, iseed=19)
     run_ops()
     run_npz()
     run_plumbing()

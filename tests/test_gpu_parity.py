@@ -485,3 +485,38 @@ def test_workspace_regrowth_keeps_results():
             qa, qb = one(p, ps, s3)[0], fresh(p, ps, s3)[0]
         assert torch.equal(qa, qb), (B, N, (qa - qb).abs().max().item())
         del fresh
+
+
+@pytest.mark.parametrize("variant,precision", [("ViT-B16", "fp16x3"), ("ViT-L16", "fp16x3"), ("ViT-B16", "fp16x2"), ("ViT-B8", "bf16x3")])
+def test_adapters_against_oracle(variant, precision):
+    """Adapter pair 0 after attention and after the MLP (transformer.py:177-194, 279-283): H/4 = 192 padded to the GEMM tile
+    (ViT-B) or 256 as is (ViT-L); other pairs are accepted and ignored like in the reference's forward; pairwise entry too."""
+    kw = dict(vit_config=dict(variant=variant, num_keep_layers=2, num_adapters=3, use_layer_scale=True, num_scales=2), num_rgs=1, num_rcabs=2)
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+    sd = synth.make_state_dict(m.spec, 91)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    patches, pos, sc = synth.make_inputs(m.spec, 3, 77, 92)
+    p, ps, s3 = split_inputs(patches, pos, sc, device=DEV)
+    with torch.no_grad():
+        q = m(p, ps, s3)[0]
+        f1, f2 = m.forward_pairwise((p[0], p[1], p[1]), (ps[0], ps[1], ps[1]), (s3[0], s3[1], s3[1]))
+    cp, cps, cs = split_inputs(patches, pos, sc)
+    q_ref = O.vtamiq_forward(O.to_torch(sd), m.spec, cp, cps, cs)[0].numpy()
+    assert gate(q.cpu().numpy(), q_ref, TOL[precision]), rel_err(q.cpu().numpy(), q_ref)
+    assert torch.equal(f1, q) and torch.equal(f2, q)
+    # the adapters matter: zeroing pair 0's up-projection changes the scores, zeroing pair 1's does not
+    sd2 = {k: v.copy() for k, v in sd.items()}
+    for k in sd2:
+        if ".adapter3." in k or ".adapter4." in k:
+            sd2[k][...] = 0
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    with torch.no_grad():
+        q_same = m(p, ps, s3)[0]
+    for k in sd2:
+        if ".adapter1.adapter.2." in k:
+            sd2[k][...] = 0
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    with torch.no_grad():
+        q_diff = m(p, ps, s3)[0]
+    assert torch.equal(q_same, q) and not torch.equal(q_diff, q)

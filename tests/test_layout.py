@@ -84,7 +84,9 @@ def test_rejected_configs():
     with pytest.raises(ValueError):
         VTAMIQ(vit_config=dict(variant="ViT-B16", use_cls_token=False))     # crashes in the reference too
     with pytest.raises(NotImplementedError):
-        VTAMIQ(vit_config=dict(variant="ViT-B16", num_adapters=2))
+        VTAMIQ(vit_config=dict(variant="ViT-B16", return_attention=True))   # S x S tensors are never materialised
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, num_adapters=2, pretrained=False))   # adapters: supported (pair 0 applied)
+    assert m.spec.num_adapters == 2 and sum("adapter" in k for k in m.state_dict()) == 16
     with pytest.raises(ValueError):
         VTAMIQ(vit_config=dict(variant="ViT-H14"))
 
@@ -174,7 +176,7 @@ def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     class Cfg(C.Structure):
         _fields_ = [(n, C.c_int32) for n in ("hidden_size", "mlp_dim", "num_heads", "num_layers", "patch_dim", "pos_grid",
                     "num_extra_tokens", "num_scales", "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs",
-                    "ca_hidden", "precision")] + [("reserved", C.c_int32 * 5)]
+                    "ca_hidden", "precision", "num_adapters")] + [("reserved", C.c_int32 * 4)]
     good = dict(hidden_size=768, mlp_dim=3072, num_heads=12, num_layers=12, patch_dim=768, pos_grid=24, num_extra_tokens=0,
                 num_scales=0, use_layer_scale=0, calibrate=1, diff_scale=1, num_rgs=4, num_rcabs=4, ca_hidden=96, precision=1)
     create = lib.vtq_create

@@ -28,8 +28,8 @@ KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "ou
 class VtqConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "hidden_size", "mlp_dim", "num_heads", "num_layers", "patch_dim", "pos_grid", "num_extra_tokens", "num_scales",
-        "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs", "ca_hidden", "precision")] + [
-        ("reserved", C.c_int32 * 5)]
+        "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs", "ca_hidden", "precision", "num_adapters")] + [
+        ("reserved", C.c_int32 * 4)]
 
 
 class VtqTensorDesc(C.Structure):

@@ -54,6 +54,7 @@ struct Slot {
     float* scale = nullptr;   // fp8 mode: destination of the rows' inverse scales
     int64_t K = 0;            // row length of a split tensor
     int64_t Kp = 0;           // row pitch of its packed planes (> K: zero-padded to the GEMM's K tile; 0 = K)
+    bool ignore = false;      // accepted and dropped: a parameter the forward never reads (adapter pairs other than pair 0)
     bool loaded = false;
 };
 
@@ -62,6 +63,11 @@ struct Layer {
     int64_t pqkv, po, p1, p2;                  // plane strides
     float *sqkv, *so, *s1, *s2;                // fp8 mode: per-output-channel inverse weight scales
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b, *g1, *g2;
+    // Adapter pair 0 (transformer.py:177-194, 260-269): site 0 after attention, site 1 after the MLP.  down: [Hq_pad, H] planes
+    // (rows >= H/4 zero), up: [H, Hq_pad] planes (K zero-padded); Hq_pad = H/4 rounded up to the GEMM tile (256)
+    void *ad_dn[2], *ad_up[2];
+    int64_t pad_dn[2], pad_up[2];
+    float *ad_bdn[2], *ad_bup[2];
 };
 // One linear stage of the DiffNet head as the skinny-MFMA kernel reads it: fp16 hi/lo planes [2][ceil16(N)][Kp] (Kp = K padded
 // to the 32-deep k-step with zeros) + fp32 bias.  The head always runs the 3-term fp16 form, whatever the encoder's precision.
@@ -79,6 +85,7 @@ struct vtq_engine {
     bool fp8 = false;                  // linear layers on e4m3 operands (MX-scaled MFMA, unit block scales): VTQ_PREC_FP8
     float* spatch = nullptr;           //   inverse weight scales of the patch embedding
     int64_t PDp = 0;                   // patch_dim rounded up to the GEMM's K granule (row pitch of the packed patches / weight)
+    int64_t Hqp = 0;                   // adapters: H / 4 rounded up to the GEMM tile (N of the down projection, K of the up projection)
     int H = 0, Mdim = 0, T = 0;
     std::vector<void*> allocs;
     std::unordered_map<std::string, Slot> slots;
@@ -157,6 +164,7 @@ int build(vtq_engine* e) {
     if (c.num_extra_tokens > 0 && add_f32(e, emb + "extra_tokens", &e->extra, (int64_t)c.num_extra_tokens * H)) return 1;
     // the patch-embedding GEMM runs on K padded to 256 (two K tiles of every operand format): 768 as is, ViT-B/8's 192 -> 256
     e->PDp = round_up(PD, 256);
+    e->Hqp = round_up(H / 4, 256);
     if (alloc_planes(e, &e->wpatch, &e->ppatch, H * e->PDp)) return 1;
     if (e->fp8 && dev_alloc(e, (void**)&e->spatch, H * sizeof(float))) return 1;
     add_split(e, emb + "patch_embeddings.weight", e->wpatch, e->ppatch, 0, H, PD, e->spatch, e->PDp);
@@ -194,6 +202,27 @@ int build(vtq_engine* e) {
             add_f32(e, p + "ffn_norm.bias", &L.ln2b, H))
             return 1;
         if (c.use_layer_scale && (add_f32(e, p + "ls1.gamma", &L.g1, H) || add_f32(e, p + "ls2.gamma", &L.g2, H))) return 1;
+        if (c.num_adapters > 0) {
+            const int64_t Hq = H / 4, Hqp = e->Hqp;
+            for (int site = 0; site < 2; ++site) {
+                const std::string q = p + "adapter" + std::to_string(site + 1) + ".adapter.";
+                if (alloc_planes(e, &L.ad_dn[site], &L.pad_dn[site], Hqp * H) || alloc_planes(e, &L.ad_up[site], &L.pad_up[site], H * Hqp) ||
+                    dev_alloc(e, (void**)&L.ad_bdn[site], Hqp * sizeof(float)))
+                    return 1;
+                HIP_TRY(hipMemset(L.ad_dn[site], 0, (size_t)Hqp * H * 2 * e->wpl));      // rows >= Hq: zero weights, zero bias -> gelu(0) = 0
+                HIP_TRY(hipMemset(L.ad_bdn[site], 0, Hqp * sizeof(float)));
+                add_split(e, q + "0.weight", L.ad_dn[site], L.pad_dn[site], 0, Hq, H);
+                { Slot sb; sb.dst = L.ad_bdn[site]; sb.numel = Hq; e->slots[q + "0.bias"] = sb; }
+                add_split(e, q + "2.weight", L.ad_up[site], L.pad_up[site], 0, H, Hq, nullptr, Hqp);
+                if (add_f32(e, q + "2.bias", &L.ad_bup[site], H)) return 1;
+            }
+            for (int a = 3; a <= 2 * c.num_adapters; ++a) {          // pairs >= 1 exist in the state_dict; the forward never reads them
+                const std::string q = p + "adapter" + std::to_string(a) + ".adapter.";
+                const int64_t n[4] = {Hq * H, Hq, H * Hq, H};
+                const char* nm[4] = {"0.weight", "0.bias", "2.weight", "2.bias"};
+                for (int k = 0; k < 4; ++k) { Slot sg; sg.numel = n[k]; sg.ignore = true; e->slots[q + nm[k]] = sg; }
+            }
+        }
     }
     if (c.diff_scale && add_f32(e, "diff_scale.gamma", &e->diff_gamma, H)) return 1;
     if (c.calibrate) {
@@ -436,6 +465,21 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
         // fp8 mode (VTQ_PREC_FP8): LayerNorm / attention / GELU outputs are e4m3 bytes with the static scales kS*, weights are
         // e4m3 rows with per-output-channel scales (de-scaled in the GEMM epilogue); the QKV output is one fp16 plane
         const bool f8m = e->fp8;
+        // Adapter pair 0 (transformer.py:279-283): h <- h + up(gelu(down(h))) on the branch output BEFORE LayerScale and the residual
+        // add.  The residual GEMM already added ls * h; the adapter's delta follows as two more GEMMs: down (N = H/4 padded to the
+        // tile, GELU epilogue) into `tmp`, up (K = the padded H/4) with the same LayerScale into x.
+        const bool adapters = c.num_adapters > 0;
+        auto adapter_site = [&](const Layer& L, int site, void* hsrc, int64_t hplane, void* tmp, int64_t tplane, const float* gamma) -> hipError_t {
+            GemmArgs d{};
+            d.A = hsrc; d.a_plane = hplane; d.lda = H; d.W = L.ad_dn[site]; d.w_plane = L.pad_dn[site];
+            d.M = M; d.N = (int)e->Hqp; d.K = H; d.bias = L.ad_bdn[site]; d.out = tmp; d.o_plane = tplane; d.ldo = (int)e->Hqp;
+            hipError_t err = launch_gemm(d, lin, EPI_BIAS_GELU, s);
+            if (err != hipSuccess) return err;
+            GemmArgs u{};
+            u.A = tmp; u.a_plane = tplane; u.lda = (int)e->Hqp; u.W = L.ad_up[site]; u.w_plane = L.pad_up[site];
+            u.M = M; u.N = H; u.K = (int)e->Hqp; u.bias = L.ad_bup[site]; u.gamma = gamma; u.x = x;
+            return launch_gemm(u, lin, EPI_RESID, s);
+        };
         const int lnf = f8m ? 2 : f16, lnp = f8m ? 1 : apl;
         { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
         if (e->dbg_stop == i * 7 + 0) return 0;
@@ -454,9 +498,16 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             Prof p(e, s, VTQ_K_OUTPROJ);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
-            a.M = M; a.N = H; a.K = H; a.bias = Ly.bo; a.gamma = Ly.g1; a.x = x;
+            a.M = M; a.N = H; a.K = H; a.bias = Ly.bo;
             a.wscale = Ly.so; a.ascale_inv = 1.0f / kSAtt;
-            HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
+            if (adapters) {                      // the branch output h itself, as operand planes for the adapter (QKV is consumed: `big` is free)
+                GemmArgs hplanes = a;
+                hplanes.out = big; hplanes.o_plane = e->big_plane; hplanes.ldo = H;
+                HIP_TRY(launch_gemm(hplanes, lin, EPI_BIAS, s));
+            }
+            a.gamma = Ly.g1; a.x = x;
+            HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));              // x += ls1 * h
+            if (adapters) HIP_TRY(adapter_site(Ly, 0, big, e->big_plane, lnb, e->ln_plane, Ly.g1));   // x += ls1 * (up(gelu(down(h))) )
         }
         if (e->dbg_stop == i * 7 + 3) return 0;
         { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
@@ -474,9 +525,16 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             Prof p(e, s, VTQ_K_FC2);
             GemmArgs a{};
             a.A = big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
-            a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2; a.gamma = Ly.g2; a.x = x;
+            a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2;
             a.wscale = Ly.s2; a.ascale_inv = 1.0f / kSGelu;
+            if (adapters) {                      // LayerNorm 2's planes are consumed: the branch output goes to `lnbuf`
+                GemmArgs hplanes = a;
+                hplanes.out = lnb; hplanes.o_plane = e->ln_plane; hplanes.ldo = H;
+                HIP_TRY(launch_gemm(hplanes, lin, EPI_BIAS, s));
+            }
+            a.gamma = Ly.g2; a.x = x;
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
+            if (adapters) HIP_TRY(adapter_site(Ly, 1, lnb, e->ln_plane, big, e->big_plane, Ly.g2));
         }
         if (e->dbg_stop == i * 7 + 6) return 0;
         if (e->trace) HIP_TRY(launch_copy_tokens(x, e->trace + (i + 1) * trace_stride, g.nseq, g.sm, T, H, s));
@@ -577,6 +635,8 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     if (c.num_heads <= 0 || c.hidden_size / c.num_heads != 64 || c.hidden_size % c.num_heads)
         return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
     if (c.mlp_dim % 256 || c.mlp_dim <= 0) return fail("mlp_dim %d must be a positive multiple of 256", c.mlp_dim);
+    if (c.num_adapters < 0 || c.num_adapters > 64) return fail("num_adapters %d", c.num_adapters);
+    if (c.num_adapters > 0 && c.precision == VTQ_PREC_FP8) return fail("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy)");
     if (c.patch_dim != 768 && c.patch_dim != 192) return fail("patch_dim %d unsupported (3*16*16 or 3*8*8)", c.patch_dim);
     if (c.num_layers < 1 || c.pos_grid < 1 || c.num_extra_tokens < 0) return fail("bad topology");
     if (c.calibrate && (c.num_rgs < 1 || c.num_rcabs < 1 || c.ca_hidden < 4 || c.ca_hidden % 4 || c.ca_hidden > 256))
@@ -629,6 +689,7 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         if (it == e->slots.end()) return fail("vtq_load_weights: unexpected tensor '%s'", d.name);
         Slot& sl = it->second;
         if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
+        if (sl.ignore) { sl.loaded = true; continue; }
         if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(d.data, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s, (int)sl.Kp));
         else if (sl.split && sl.Kp != sl.K)
             HIP_TRY(launch_split_rows_pad(d.data, sl.dst, sl.plane, (int)(sl.numel / sl.K), (int)sl.K, (int)sl.Kp, e->f16, e->wpl, s));
@@ -746,7 +807,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     // the trace tap needs every token row of the last layer; sequences longer than the CLS kernel's LDS score buffer run the
     // full last layer instead (same result)
     // (fp8 mode runs the full last layer: its CLS row then goes through the same e4m3 GEMMs as every other row)
-    const bool prune = e->cls_prune && !e->trace && !e->fp8 && g.S <= cls_attention_max_seq();
+    const bool prune = e->cls_prune && !e->trace && !e->fp8 && c.num_adapters == 0 && g.S <= cls_attention_max_seq();
     if (run_encoder(e, g, s, prune)) return 1;
 
     // ---- head (vtamiq.py:104-117) ------------------------------------------------------------------------------

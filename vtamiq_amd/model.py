@@ -78,6 +78,12 @@ class _Mlp(_Params):                        # MLP (transformer.py:197-210)
         self.fc1, self.fc2 = nn.Linear(H, M), nn.Linear(M, H)
 
 
+class _Adapter(_Params):                    # Adapter (transformer.py:177-194): x + Linear(H/4 -> H)(GELU(Linear(H -> H/4)(x)))
+    def __init__(self, H):
+        super().__init__()
+        self.adapter = nn.Sequential(nn.Linear(H, H // 4), nn.Identity(), nn.Linear(H // 4, H))
+
+
 class _EncoderLayer(_Params):               # EncoderLayer (transformer.py:246-273)
     def __init__(self, spec: ModelSpec):
         super().__init__()
@@ -86,6 +92,9 @@ class _EncoderLayer(_Params):               # EncoderLayer (transformer.py:246-2
         self.ffn_norm = nn.LayerNorm(H, eps=1e-6)
         self.ffn = _Mlp(H, spec.mlp_dim)
         self.attn = _Attn(H)
+        self.use_adapters = spec.num_adapters > 0
+        for a in range(1, 2 * spec.num_adapters + 1):          # adapter1 / adapter2 = pair 0 (the one the forward uses), ...
+            self.add_module(f"adapter{a}", _Adapter(H))
         if spec.use_layer_scale:
             self.ls1, self.ls2 = _Gamma(H), _Gamma(H)
 
@@ -102,7 +111,7 @@ class _Transformer(_Params):                # VisionTransformer (transformer.py:
         super().__init__()
         self.hidden_size = spec.hidden_size
         self.use_layer_scale = spec.use_layer_scale
-        self.use_adapters = False
+        self.use_adapters = spec.num_adapters > 0
         self.embeddings = _Embeddings(spec)
         self.encoder = _Encoder(spec)
         for m in self.modules():            # _init_weights (transformer.py:670-678)
@@ -163,6 +172,9 @@ class VTAMIQ(nn.Module):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
         self.precision = precision
+        if precision == "fp8" and self.spec.num_adapters > 0:
+            raise NotImplementedError("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy of the "
+                                      "branch output); use a 16-bit precision")
         self._engine = None
         self._engine_device = None
         self._weights_sig = None
@@ -275,7 +287,7 @@ class VTAMIQ(nn.Module):
                 patch_dim=s.patch_dim, pos_grid=s.pos_grid, num_extra_tokens=s.num_extra_tokens,
                 num_scales=s.num_scales if s.use_scale_embedding else 0, use_layer_scale=int(s.use_layer_scale),
                 calibrate=int(s.calibrate), diff_scale=int(s.diff_scale), num_rgs=s.num_rgs, num_rcabs=s.num_rcabs,
-                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.precision])
+                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.precision], num_adapters=s.num_adapters)
             h = C.c_void_p()
             _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
             self._engine, self._engine_device = h, device

@@ -48,6 +48,7 @@ class ModelSpec:
     num_extra_tokens: int = 0
     num_scales: int = 0           # scale embedding active iff num_scales > 1 (transformer.py:500)
     use_layer_scale: bool = False
+    num_adapters: int = 0         # Adapter pairs per layer (transformer.py:177-194, 260-269); the forward uses pair 0 (backbone.py:54-57)
     # VTAMIQ head
     calibrate: bool = True
     diff_scale: bool = True
@@ -89,7 +90,10 @@ class ModelSpec:
     def flops_per_image(self, num_patches: int) -> float:
         H, M, L = self.hidden_size, self.mlp_dim, self.num_layers
         S = self.seq_len(num_patches)
-        return 2.0 * num_patches * self.patch_dim * H + L * (8.0 * S * H * H + 4.0 * S * H * M + 4.0 * S * S * H)
+        f = 2.0 * num_patches * self.patch_dim * H + L * (8.0 * S * H * H + 4.0 * S * H * M + 4.0 * S * S * H)
+        if self.num_adapters > 0:                       # two bottleneck adapters per layer: H -> H/4 -> H each
+            f += L * 2.0 * (4.0 * S * H * (H // 4))
+        return f
 
     def flops_head(self) -> float:
         H = self.hidden_size
@@ -105,7 +109,7 @@ class ModelSpec:
         """Dense flops the engine actually executes per pair.  With the CLS-only last layer (only token 0 is consumed,
         vtamiq.py:107-108) the last layer keeps the K/V projections for every row and runs Q, attention, out-proj and the
         MLP for one row per image."""
-        if not cls_prune:
+        if not cls_prune or self.num_adapters > 0:      # the engine runs the full last layer when adapters are on
             return self.flops_per_pair(num_patches)
         H, M = self.hidden_size, self.mlp_dim
         S = self.seq_len(num_patches)
@@ -146,6 +150,12 @@ class ModelSpec:
             for nm in ("query", "key", "value", "out"):
                 out.append((p + f"attn.{nm}.weight", (H, H), "matrix"))
                 out.append((p + f"attn.{nm}.bias", (H,), "bias"))
+            for a in range(1, 2 * self.num_adapters + 1):           # adapter{2j+1} (after attention), adapter{2j+2} (after the MLP)
+                q = f"{p}adapter{a}.adapter."
+                out.append((q + "0.weight", (H // 4, H), "matrix"))
+                out.append((q + "0.bias", (H // 4,), "bias"))
+                out.append((q + "2.weight", (H, H // 4), "matrix"))
+                out.append((q + "2.bias", (H,), "bias"))
             if self.use_layer_scale:
                 out.append((p + "ls1.gamma", (H,), "gamma"))
                 out.append((p + "ls2.gamma", (H,), "gamma"))
@@ -193,8 +203,9 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
         raise NotImplementedError("use_patch_embedding=False (pre-embedded input) is outside the accelerated path")
     if not vc.pop("use_pos_embedding", True):
         raise NotImplementedError("use_pos_embedding=False is outside the accelerated path")
-    if vc.pop("num_adapters", 0) > 0:
-        raise NotImplementedError("num_adapters>0 (Adapter, transformer.py:177-194) is outside the accelerated path")
+    num_adapters = int(vc.pop("num_adapters", 0))
+    if num_adapters < 0:
+        raise ValueError("num_adapters must be >= 0")
     if vc.pop("return_layers", False) or vc.pop("return_attention", False):
         raise NotImplementedError("return_layers/return_attention materialise S*S tensors; not provided by the HIP path")
     vc.pop("pretrained", None)                          # weights arrive through load_state_dict
@@ -207,7 +218,7 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
         variant=variant, hidden_size=cfg["hidden_size"], mlp_dim=cfg["mlp_dim"], num_heads=cfg["num_heads"],
         num_layers=num_layers, patch_size=cfg["patch_size"], pos_grid=cfg["img_dim"] // cfg["patch_size"],
         num_extra_tokens=int(vc.pop("num_extra_tokens", 0)), num_scales=int(vc.pop("num_scales", 0)),
-        use_layer_scale=bool(vc.pop("use_layer_scale", False)),
+        use_layer_scale=bool(vc.pop("use_layer_scale", False)), num_adapters=num_adapters,
         calibrate=bool(calibrate), diff_scale=bool(diff_scale), num_rgs=int(num_rgs), num_rcabs=int(num_rcabs),
         ca_reduction=int(ca_reduction))
     if vc:
