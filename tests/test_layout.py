@@ -83,8 +83,8 @@ def test_rejected_configs():
     from vtamiq_amd import VTAMIQ
     with pytest.raises(ValueError):
         VTAMIQ(vit_config=dict(variant="ViT-B16", use_cls_token=False))     # crashes in the reference too
-    with pytest.raises(NotImplementedError):
-        VTAMIQ(vit_config=dict(variant="ViT-B16", return_attention=True))   # S x S tensors are never materialised
+    with pytest.warns(UserWarning, match="return_layers"):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, return_attention=True, pretrained=False))   # accepted: VTAMIQ.forward discards them
     m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, num_adapters=2, pretrained=False))   # adapters: supported (pair 0 applied)
     assert m.spec.num_adapters == 2 and sum("adapter" in k for k in m.state_dict()) == 16
     with pytest.raises(ValueError):

@@ -206,8 +206,13 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
     num_adapters = int(vc.pop("num_adapters", 0))
     if num_adapters < 0:
         raise ValueError("num_adapters must be >= 0")
-    if vc.pop("return_layers", False) or vc.pop("return_attention", False):
-        raise NotImplementedError("return_layers/return_attention materialise S*S tensors; not provided by the HIP path")
+    rl, ra = vc.pop("return_layers", False), vc.pop("return_attention", False)
+    if rl or ra:
+        # forward_vit would return per-layer states / (B, h, S, S) attention maps, which VTAMIQ.forward discards (vtamiq.py:100-101:
+        # `feats, _, _ = ...`): the scores are unaffected, so the options are accepted and nothing is materialised
+        import warnings
+        warnings.warn("return_layers / return_attention have no effect on VTAMIQ.forward's outputs and are not materialised by the "
+                      "HIP path (vtq_set_token_trace taps the token rows of every layer for debugging)")
     vc.pop("pretrained", None)                          # weights arrive through load_state_dict
     vc.pop("path_drop_prob", None)                      # encoder DropPath is identity in the reference (transformer.py:272-273)
     num_keep = vc.pop("num_keep_layers", -1)
