@@ -121,7 +121,7 @@ def fc1_traffic(precision, B):
 LIVE_EXTRA = {}      # filled by live_fc1_traffic: counters of the third pass (MFMA-pipe utilisation)
 
 
-def live_fc1_traffic(precision, B, S, timeout_s=150.0):
+def live_fc1_traffic(precision, B, S, timeout_s=75.0):
     """FETCH_SIZE and WRITE_SIZE of the fc1 GEMM measured NOW, on this box: two child processes (separate --pmc passes, as the
     MI355X guide prescribes; --kernel-trace only beside them; the program itself after `--`) of
     `rocprofv3 --pmc <counter> --kernel-trace -- python3 tools/gemm_bench.py --only fc1 --rounds 1 --fmt <precision>`,
