@@ -127,6 +127,12 @@ int  vtq_set_token_trace(vtq_handle h, float* buf);
  * big = QKV / fc1 output planes, in the layouts DESIGN.md section 3 gives for the engine's precision. */
 int  vtq_debug_stop_after(vtq_handle h, int32_t stage);
 int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t* rows);
+/* Clock diagnostic of the GEMM kernel (MI355X_MICROARCH.md 'DVFS give-back' item 6).  Only a library built with -DVTQ_GEMM_DIAG
+ * (tools/build_abl.sh) executes stamps; the shipped build returns 0 and does nothing.  buf = 256 x 64 uint64 of device memory that
+ * nothing else reads: per workgroup {sum over its K loops of s_memtime, of s_memrealtime; the same two over the whole kernel;
+ * tiles; XCC id; then per wave the cycles spent in the epilogue conversion, copy-out and waits}; shadow = dummy VALU instructions (x8) issued in every LDS-read phase of the main loop (what vector work beside
+ * the partner wave's MFMAs costs).  Returns 1 in a diagnostic build. */
+int  vtq_debug_gemm_diag(void* buf, int32_t shadow);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
 #define VTQ_K_CONVERT  0

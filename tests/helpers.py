@@ -12,6 +12,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 E2E_CASES = ["c1_b2_n50", "refdefault_b2_n64", "scales3_b2_n40", "unaligned_b3_n50", "c2shape_b4_n500",
              "vitl_b2_n70", "nocalib_b2_n30", "vitb8_b2_n90", "adapters_b2_n40"]
+# the reference run on stress_state weights (trained-like statistics: peaked softmax, outlier channels), qk = 3 and 5
+STRESS_CASES = ["stress3_b3_n90", "stress5_b3_n90"]
 
 
 def load_case(name):
@@ -19,7 +21,7 @@ def load_case(name):
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     kw = json.loads(str(g["kwargs"]))
     spec = make_spec(**json.loads(json.dumps(kw)))
-    sd = synth.make_state_dict(spec, int(g["wseed"]))
+    sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"])) if "stress_qk" in g else synth.make_state_dict(spec, int(g["wseed"]))
     patches, pos, scales = synth.make_inputs(spec, int(g["B"]), int(g["N"]), int(g["iseed"]),
                                              aligned=bool(int(g.get("aligned", 1))))
     # generator drift guard: the fixtures were produced from exactly these tensors

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, gate_error, load_case, rel_err, split_inputs, stress_state
+from tests.helpers import E2E_CASES, STRESS_CASES, gate_error, load_case, rel_err, split_inputs, stress_state
 from vtamiq_amd import VTAMIQ, synth
 from vtamiq_amd.predict import get_data_tuple, predict
 
@@ -54,6 +54,25 @@ def test_golden(name, precision):
     print(f"\n[{name} {precision}] {e}")
     assert np.isfinite(q.cpu().numpy()).all()
     assert gate(q.cpu().numpy(), g["q"], TOL[precision]), e
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+@pytest.mark.parametrize("name", STRESS_CASES)
+def test_golden_trained_like_statistics(name, precision):
+    """Goldens captured from the REFERENCE on stress_state weights (peaked softmax, outlier channels; qk = 3 and 5): the parity
+    claim off the flat random init, pinned by the reference itself.  Gate: RAW per-score relative error against
+    the reference's fp32 scores, 1e-3 for the parity mode (the reference's own fp32 evaluation is 1.2e-5 / 9.0e-5 from its float64
+    scores on these two cases, tests/test_oracle_golden.py); the float64 scores are reported beside it."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    model = build(kw, sd, precision)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    with torch.no_grad():
+        q, _ = model(p, ps, sc)
+    q = q.cpu().numpy()
+    e, e64 = rel_err(q, g["q"]), rel_err(q, g["q64"])
+    print(f"\n[{name} {precision}] vs reference fp32 {e['max_rel']:.2e}, vs reference fp64 {e64['max_rel']:.2e}")
+    assert np.isfinite(q).all()
+    assert e["max_rel"] < TOL[precision] and e64["max_rel"] < TOL[precision], (e, e64)
 
 
 @pytest.mark.parametrize("precision", ALL_MODES)

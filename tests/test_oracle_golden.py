@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, GOLDEN, load_case, split_inputs, rel_err
+from tests.helpers import E2E_CASES, STRESS_CASES, GOLDEN, load_case, split_inputs, rel_err
 import os
 
 # fp32 op-order differences between the restatement and the reference modules stay below this
@@ -20,6 +20,28 @@ def test_e2e_q(name):
     e = rel_err(q.numpy(), g["q"])
     assert e["max_rel_rms"] < ORACLE_RTOL, e
     assert e["max_abs"] < 1e-6, e
+
+
+@pytest.mark.parametrize("name", STRESS_CASES)
+def test_e2e_q_trained_like_statistics(name):
+    """The oracle against the REFERENCE run on stress_state weights (peaked softmax, outlier channels).
+    Evaluated in float64 the restatement reproduces the reference's float64 scores to 1e-12 (it IS the same algorithm).  In float32
+    two evaluations of this model differ through their operation order alone: the reference is 1.2e-5 (qk = 3) / 9.0e-5 (qk = 5)
+    from its own float64 scores, the oracle 8.8e-6 / 4.9e-5; the fp32-vs-fp32 bound is therefore 3e-4 raw, and each against
+    float64 1.5e-4."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales)
+    q, aux = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)
+    e = rel_err(q.numpy(), g["q"])
+    e64 = rel_err(q.numpy(), g["q64"])
+    r64 = rel_err(g["q"], g["q64"])
+    print(name, "oracle32-ref32", e["max_rel"], "oracle32-ref64", e64["max_rel"], "ref32-ref64", r64["max_rel"])
+    assert e["max_rel"] < 3e-4 and e64["max_rel"] < 1.5e-4 and r64["max_rel"] < 1.5e-4, (e, e64, r64)
+    sd64 = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    p64, ps64, sc64 = split_inputs(patches, pos, scales, dtype=torch.float64)
+    q64 = O.vtamiq_forward(sd64, spec, p64, ps64, sc64)[0]
+    assert q64.dtype == torch.float64
+    assert rel_err(q64.numpy(), g["q64"])["max_rel"] < 1e-10
 
 
 def test_per_layer_tokens_c1():

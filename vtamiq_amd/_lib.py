@@ -51,6 +51,7 @@ SIGNATURES = {
     "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtq_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "vtq_debug_gemm_diag": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
@@ -97,6 +98,8 @@ def load() -> C.CDLL:
     except OSError as e:
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
+        if name.startswith("vtq_debug_") and os.environ.get("VTQ_LIB_PATH") and not hasattr(lib, name):
+            continue                     # an A/B build of an older tree (tools/_abl) may predate a debug hook; the shipped library may not
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -730,6 +730,11 @@ int vtq_debug_buffers(vtq_handle e, void** x, void** lnbuf, void** big, int64_t*
     return 0;
 }
 
+int vtq_debug_gemm_diag(void* buf, int32_t shadow) {
+    gemm_set_diag((unsigned long long*)buf, shadow);
+    return gemm_is_diag_build() ? 1 : 0;
+}
+
 int vtq_profile_enable(vtq_handle e, uint32_t mask) {
     if (!e) return fail("null handle");
     e->prof_mask = mask;

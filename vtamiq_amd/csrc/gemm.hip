@@ -76,9 +76,19 @@ template <typename T, int OPL, int EPI, int MH> constexpr int epilogue_ops_of() 
 }
 
 // T = OUTPUT element type of the 16-bit / 8-bit forms; SCALED: fp8 operands (acc * wscale[n] * ascale_inv before the bias)
+#ifdef VTQ_GEMM_DIAG
+struct EpiDiag { unsigned long long conv, copy, wait; };
+#define VTQ_EPI_T0() unsigned long long dg_e0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_e0) :: "memory");
+#define VTQ_EPI_T1(field) { unsigned long long dg_e1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_e1) :: "memory"); ed.field += dg_e1 - dg_e0; dg_e0 = dg_e1; }
+#else
+struct EpiDiag {};
+#define VTQ_EPI_T0()
+#define VTQ_EPI_T1(field)
+#endif
+
 template <typename T, int OPL, int EPI, int MH, bool SCALED>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
-                                            int fr, int fq, int64_t m0, int n0) {
+                                            int fr, int fq, int64_t m0, int n0, EpiDiag& ed) {
     typedef typename Vec<T>::x4 tx4;
     // opaque copies of the lane indices: every per-lane address below is then formed HERE, after the main loop, instead of being
     // hoisted above it and kept (or spilled) across it
@@ -198,6 +208,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                             }
                             if constexpr (NP == 1) {
                                 h = tx4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                            } else if constexpr (std::is_same<T, f16>::value) {
+                                tx4 l;
+                                split4_f16(v, h, l);           // 6 vector instructions for the four values (dev_common.h)
+                                lo[li] = l;
                             } else {
                                 tx4 l;
 #pragma unroll
@@ -225,15 +239,27 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         // Within an interval the two wave groups (the two waves of every SIMD) run the two steps in OPPOSITE order -- they touch
         // different images, so either order is valid -- so that one wave's VALU conversion runs while its SIMD partner sits in
         // the store-issue queue, instead of both queueing and then both converting.
+        VTQ_EPI_T0()
         convert(0);
+        VTQ_EPI_T1(conv)
         interval_end();
+        VTQ_EPI_T1(wait)
 #pragma unroll
         for (int pass = 1; pass < NPASS; ++pass) {
-            if (wr == 0) { copy_out(pass - 1); convert(pass); }
-            else { convert(pass); copy_out(pass - 1); }
+#if defined(VTQ_EPI_ORDER) && VTQ_EPI_ORDER == 1          // measurement builds: both wave groups copy first / convert first
+            const bool copy_first = true;
+#elif defined(VTQ_EPI_ORDER) && VTQ_EPI_ORDER == 2
+            const bool copy_first = false;
+#else
+            const bool copy_first = (wr == 0);
+#endif
+            if (copy_first) { copy_out(pass - 1); VTQ_EPI_T1(copy) convert(pass); VTQ_EPI_T1(conv) }
+            else { convert(pass); VTQ_EPI_T1(conv) copy_out(pass - 1); VTQ_EPI_T1(copy) }
             interval_end();
+            VTQ_EPI_T1(wait)
         }
         copy_out(NPASS - 1);
+        VTQ_EPI_T1(copy)
     } else if constexpr (EPI == EPI_RESID) {
         // chunk (mh, mi): the 32 rows {mh*128 + wr*64 + mi*16 + fr}, image row = wr*16 + fr, fp32; the residual rows of chunk
         // k are requested one interval before they are needed
@@ -493,6 +519,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     // vmcnt -- i.e. the previous tile's epilogue stores -- at the top of every tile
     const __attribute__((address_space(4))) int* sch = (const __attribute__((address_space(4))) int*)p.sched;
     const int it_beg = sch[blockIdx.x], it_end = sch[blockIdx.x + 1];
+    EpiDiag epi_diag{};
+#ifdef VTQ_GEMM_DIAG
+    // Diagnostic build only (MI355X_MICROARCH.md 'DVFS give-back' item 6): shader-clock and 100 MHz real-time stamps around every
+    // K loop and around the whole kernel, summed in scalar registers and written to a buffer nothing else reads.
+    unsigned long long dg_lt = 0, dg_lr = 0, dg_t0, dg_r0, dg_kt0, dg_kr0;
+    auto stamp = [&](unsigned long long& t, unsigned long long& r) {
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) :: "memory");
+    };
+    stamp(dg_kt0, dg_kr0);
+    float dg_v[4] = {1.0f, 1.5f, 2.0f, 2.5f};
+    auto shadow_valu = [&]() {           // p.shadow x 8 independent FMAs in the load phase (beside the partner wave's MFMA cluster)
+        for (int i = 0; i < p.shadow; ++i)
+            asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1\n\t"
+                         "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1"
+                         : "+v"(dg_v[0]), "+v"(dg_v[1]), "+v"(dg_v[2]), "+v"(dg_v[3]));
+    };
+#define VTQ_DIAG_SHADOW() shadow_valu();
+#define VTQ_DIAG_LOOP_BEGIN() stamp(dg_t0, dg_r0);
+#define VTQ_DIAG_LOOP_END() { unsigned long long t1, r1; stamp(t1, r1); dg_lt += t1 - dg_t0; dg_lr += r1 - dg_r0; }
+#else
+#define VTQ_DIAG_SHADOW()
+#define VTQ_DIAG_LOOP_BEGIN()
+#define VTQ_DIAG_LOOP_END()
+#endif
     bool chained = false;       // this tile's K tile 0 (both groups) was staged by the previous tile; K tile 1's g2 is still to issue
     for (int it = it_beg; it < it_end; ++it) {
         const int d = sch[it];
@@ -534,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             __builtin_amdgcn_s_barrier();
             if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
 
+            VTQ_DIAG_LOOP_BEGIN()
             for (int kt = 0; kt < nkt; ++kt) {
                 const char* buf = smem + (kt & 1) * BUF_B;
                 // ---- phase A --------------------------------------------------------------------------------------------
@@ -550,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
                 } else {
                     wait_vm<0>();
                 }
+                VTQ_DIAG_SHADOW()
                 VTQ_SYNC_OPEN_WAITED()
                 mma(acc[0][0], fb0);
                 mma(acc[0][1], fb1);
@@ -563,14 +615,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
                     if (has_next) { stage(Agn, Wgn, 0, 0); stage(Agn, Wgn, 0, 1); stage(Agn, Wgn, 0, 2); wait_vm<GO + GE>(); }
                     else wait_vm<GO>();
                 }                                             // last K tile: nothing of this tile is left to land
+                VTQ_DIAG_SHADOW()
                 VTQ_SYNC_OPEN_WAITED()
                 mma(acc[1][1], fb1);
                 mma(acc[1][0], fb0);
                 VTQ_SYNC_CLOSE()
             }
+            VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
             if (!(p.flags & GEMM_FLAG_NO_EPILOGUE))
-                pp_epilogue<TO, OPL, EPI, 2, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+                pp_epilogue<TO, OPL, EPI, 2, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
@@ -609,6 +663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             __builtin_amdgcn_s_barrier();
             if (wr == 1) __builtin_amdgcn_s_barrier();
             int slot = 0;                                      // kt % 3
+            VTQ_DIAG_LOOP_BEGIN()
             for (int kt = 0; kt < nkt; ++kt) {
                 const char* buf = smem + slot * BUF_H;
                 read_b(buf + 1 * REG_B, fb0);
@@ -617,14 +672,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
                 const int nslot = slot == 0 ? 2 : slot - 1;    // (kt + 2) % 3
                 if (kt + 2 < nkt) { stage_h(kt + 2, nslot); wait_vm<GH>(); }
                 else wait_vm<0>();
+                VTQ_DIAG_SHADOW()
                 VTQ_SYNC_OPEN_WAITED()
                 mma(acc[0][0], fb0);
                 mma(acc[0][1], fb1);
                 VTQ_SYNC_CLOSE()
                 slot = slot == 2 ? 0 : slot + 1;
             }
+            VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();
-            pp_epilogue<TO, OPL, EPI, 1, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0);
+            pp_epilogue<TO, OPL, EPI, 1, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             chained = false;
             if (it + 1 < it_end) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -632,6 +689,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
         }
     }
+#ifdef VTQ_GEMM_DIAG
+    {
+        unsigned long long t1, r1;
+        stamp(t1, r1);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("" ::"v"(dg_v[0]), "v"(dg_v[1]), "v"(dg_v[2]), "v"(dg_v[3]));
+        if (p.diag && (threadIdx.x & 63) == 0) {
+            unsigned long long* d = p.diag + (size_t)blockIdx.x * 64;
+            if (threadIdx.x == 0) { d[0] = dg_lt; d[1] = dg_lr; d[2] = t1 - dg_kt0; d[3] = r1 - dg_kr0; d[4] = (unsigned long long)(it_end - it_beg); d[5] = xcc & 0xf; }
+            unsigned long long* w = d + 8 + (threadIdx.x >> 6) * 4;          // per wave: cycles in convert / copy-out / interval-end waits
+            w[0] = epi_diag.conv; w[1] = epi_diag.copy; w[2] = epi_diag.wait;
+        }
+    }
+#endif
+#undef VTQ_DIAG_SHADOW
+#undef VTQ_DIAG_LOOP_BEGIN
+#undef VTQ_DIAG_LOOP_END
 #undef VTQ_SYNC_OPEN_WAITED
 #undef VTQ_SYNC_CLOSE
 }
@@ -775,6 +850,9 @@ hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds) {
     return hipSuccess;
 }
 
+unsigned long long* g_diag_buf = nullptr;
+int g_diag_shadow = 0;
+
 int env_flags() {
     static const int f = [] { const char* v = getenv("VTQ_GEMM_FLAGS"); return v ? atoi(v) : 0; }();   // measurement knobs (kernels.h)
     return f;
@@ -804,6 +882,8 @@ template <typename T, int TERMS, int EPI> hipError_t launch_t(GemmArgs a, hipStr
     e = schedule_for(a.M / 256, a.N / 256, cg, (a.flags & GEMM_FLAG_DYNAMIC) != 0, ds);
     if (e != hipSuccess) return e;
     a.sched = ds.dev;
+    a.diag = g_diag_buf;
+    a.shadow = g_diag_shadow;
     hipLaunchKernelGGL((gemm_pp2_kernel<T, TERMS, EPI>), dim3(ds.nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
@@ -819,6 +899,16 @@ template <typename T, int TERMS> hipError_t launch_e(const GemmArgs& a, int epil
 }
 
 }  // namespace
+
+extern unsigned long long* g_attn_diag;        // attention.hip: diagnostic builds sum their phase stamps into the first words of the same buffer
+void gemm_set_diag(unsigned long long* buf, int shadow) { g_diag_buf = buf; g_diag_shadow = shadow; g_attn_diag = buf; }
+bool gemm_is_diag_build() {
+#ifdef VTQ_GEMM_DIAG
+    return true;
+#else
+    return false;
+#endif
+}
 
 std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
     return build_schedule(ntm, ntn, column_group(ntn, K, wpl));

@@ -58,9 +58,15 @@ struct GemmArgs {
     const float* wscale; float ascale_inv; float out_scale;
     const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
     int flags;                                    // set by launch_gemm: GEMM_FLAG_*
+    // diagnostic builds (-DVTQ_GEMM_DIAG, tools/build_abl.sh) only; set by launch_gemm from gemm_set_diag, never read otherwise:
+    unsigned long long* diag;                     //   per workgroup 8 words: K-loop and whole-kernel s_memtime / s_memrealtime sums
+    int shadow;                                   //   dummy v_fma_f32 issued in every load phase (x8): the price of VALU work beside the partner's MFMAs
 };
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
+// diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
+void gemm_set_diag(unsigned long long* buf, int shadow);
+bool gemm_is_diag_build();
 // Persistent schedule of a (ntm x ntn)-tile GEMM with K columns and wpl weight planes (host only): 257 offsets, then the
 // per-workgroup lists; entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half
 std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);

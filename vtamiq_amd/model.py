@@ -22,7 +22,15 @@ from . import _lib
 from .spec import ModelSpec, make_spec
 
 _PRECISIONS = _lib.PRECISIONS
-DEFAULT_PRECISION = "fp16x3"
+# "auto" (the default of the drop-in model): run the parity mode fp16x3, read the engine's error word after every forward (one
+# 4-byte D2H + stream sync: the caller's q.cpu() / loss pays the same sync a moment later) and
+#   * raise IndexError for a position outside [0, 1), as the reference's table lookup does (transformer.py:417-421);
+#   * when an operand left the fp16 range (|v| > 65504: non-finite CLS difference) switch THIS model to "bf16x3" (fp32 range,
+#     same 3-MFMA split) with a warning and re-run the call -- the fp32 reference returns finite scores there (train.py:602-607),
+#     so must a drop-in.  The switch is sticky: the overflow comes from the checkpoint's activation scale.
+# An explicit precision keeps the forward asynchronous (bench.py, throughput runs); check_inputs() reports on demand.
+DEFAULT_PRECISION = "auto"
+AUTO_FIRST, AUTO_FALLBACK = "fp16x3", "bf16x3"
 
 
 class _Params(nn.Module):
@@ -169,14 +177,16 @@ class VTAMIQ(nn.Module):
         precision = precision or os.environ.get("VTAMIQ_PRECISION", DEFAULT_PRECISION)
         if precision == "fp8w":                 # alias used by the round-1 review for BASELINE configs[4] ("fp8 weights"): same mode
             precision = "fp8"
-        if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
+        if precision != "auto" and precision not in _PRECISIONS:
+            raise ValueError(f"precision must be 'auto' or one of {sorted(_PRECISIONS)}, got {precision!r}")
         self.precision = precision
+        self._auto_fallback = False             # "auto" only: an fp16 operand overflowed, the engine now runs AUTO_FALLBACK
         if precision == "fp8" and self.spec.num_adapters > 0:
             raise NotImplementedError("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy of the "
                                       "branch output); use a 16-bit precision")
         self._engine = None
         self._engine_device = None
+        self._engine_precision = None
         self._weights_sig = None
         self._warned_grad = False
         # VTAMIQ_VALIDATE_INPUTS=1 (or model.validate_inputs = True): synchronise after every forward and raise IndexError when a
@@ -190,10 +200,14 @@ class VTAMIQ(nn.Module):
             if os.path.exists(path):
                 print("ViT: Loading pretrained transformer from path:", path)          # transformer.py:623
                 load_vit_npz(self, path)
-            else:
+            elif os.environ.get("VTAMIQ_ALLOW_MISSING_WEIGHTS", "0") == "1":
                 warnings.warn(f"[VTAMIQ] pretrained=True but '{path}' does not exist: the transformer keeps its random "
-                              "initialisation (the reference raises FileNotFoundError here, transformer.py:622-624); pass "
-                              "vit_config['pretrained']=False, vit_config['vit_weights_path'] or load a checkpoint")
+                              "initialisation (VTAMIQ_ALLOW_MISSING_WEIGHTS=1)")
+            else:                                  # np.load in the reference (transformer.py:622-624)
+                raise FileNotFoundError(
+                    f"[VTAMIQ] pretrained=True but the ViT checkpoint '{path}' does not exist.  Pass vit_config['vit_weights_path'], "
+                    "set VTAMIQ_VIT_WEIGHTS, or vit_config['pretrained']=False when a full checkpoint is loaded afterwards "
+                    "(VTAMIQ_ALLOW_MISSING_WEIGHTS=1 keeps the random initialisation with a warning)")
 
     # ---- reference surface --------------------------------------------------------------------------------
     @property
@@ -273,12 +287,45 @@ class VTAMIQ(nn.Module):
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
         if flags.value & 2:
             raise FloatingPointError(
-                f"non-finite encoder output in precision={self.precision!r}: an activation or weight left the operand format's range "
+                f"non-finite encoder output in precision={self.engine_precision!r}: an activation or weight left the operand format's range "
                 "(fp16 modes: |v| <= 65504) or the inputs held inf / NaN; precision='bf16x3' has the fp32 range")
+
+    @property
+    def engine_precision(self) -> str:
+        """The numerics mode the engine runs: `precision`, or for "auto" fp16x3 until an operand overflow switched it to bf16x3."""
+        if self.precision != "auto":
+            return self.precision
+        return AUTO_FALLBACK if self._auto_fallback else AUTO_FIRST
+
+    def _read_flags(self) -> int:
+        flags = C.c_int32(0)
+        with torch.cuda.device(self._engine_device):
+            stream = torch.cuda.current_stream(self._engine_device).cuda_stream
+            _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
+        return flags.value
+
+    def _launch_checked(self, device, launch):
+        """Enqueue one forward (`launch(lib)`) and apply the model's input / range policy (see DEFAULT_PRECISION)."""
+        launch(self._ensure_engine(device))
+        if self.precision == "auto":
+            flags = self._read_flags()
+            if flags & 2 and not self._auto_fallback:
+                warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
+                              f"{AUTO_FIRST!r}: this model now runs {AUTO_FALLBACK!r} (fp32 operand range, the same 3-MFMA split; "
+                              "the call is repeated)")
+                self._auto_fallback = True
+                launch(self._ensure_engine(device))
+                flags = (flags & 1) | self._read_flags()
+            if flags & 1:
+                raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
+            if flags & 2:
+                raise FloatingPointError("non-finite encoder output in precision 'bf16x3': the inputs or weights hold inf / NaN")
+        elif self.validate_inputs:
+            self.check_inputs()
 
     def _ensure_engine(self, device: torch.device):
         lib = _lib.load()
-        if self._engine is not None and self._engine_device != device:
+        if self._engine is not None and (self._engine_device != device or self._engine_precision != self.engine_precision):
             self._release_engine()
         if self._engine is None:
             s = self.spec
@@ -287,10 +334,10 @@ class VTAMIQ(nn.Module):
                 patch_dim=s.patch_dim, pos_grid=s.pos_grid, num_extra_tokens=s.num_extra_tokens,
                 num_scales=s.num_scales if s.use_scale_embedding else 0, use_layer_scale=int(s.use_layer_scale),
                 calibrate=int(s.calibrate), diff_scale=int(s.diff_scale), num_rgs=s.num_rgs, num_rcabs=s.num_rcabs,
-                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.precision], num_adapters=s.num_adapters)
+                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.engine_precision], num_adapters=s.num_adapters)
             h = C.c_void_p()
             _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
-            self._engine, self._engine_device = h, device
+            self._engine, self._engine_device, self._engine_precision = h, device, self.engine_precision
             self._weights_sig = None
         sig = self._signature()
         if sig != self._weights_sig:
@@ -354,24 +401,24 @@ class VTAMIQ(nn.Module):
             if scales_ref.numel() != B * N or scales_dist.numel() != B * N:
                 raise ValueError("scales must be two (B,N) tensors")
         with torch.cuda.device(device):
-            lib = self._ensure_engine(device)
             pr, pd = self._prep(patches_ref, device), self._prep(patches_dist, device)
             qr, qd = self._prep(pos_ref, device), self._prep(pos_dist, device)
             sr = self._prep(scales_ref, device) if use_scales else None
             sdist = self._prep(scales_dist, device) if use_scales else None
             q = torch.empty(B, device=device, dtype=torch.float32)
             stream = torch.cuda.current_stream(device).cuda_stream
-            if _trace is not None:
-                _lib.check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
-            try:
-                _lib.check(lib.vtq_forward(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
-                                           sr.data_ptr() if use_scales else None, sdist.data_ptr() if use_scales else None,
-                                           B, N, q.data_ptr(), stream))
-            finally:
+
+            def launch(lib):
                 if _trace is not None:
-                    lib.vtq_set_token_trace(self._engine, None)
-        if self.validate_inputs:
-            self.check_inputs()
+                    _lib.check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
+                try:
+                    _lib.check(lib.vtq_forward(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
+                                               sr.data_ptr() if use_scales else None, sdist.data_ptr() if use_scales else None,
+                                               B, N, q.data_ptr(), stream))
+                finally:
+                    if _trace is not None:
+                        lib.vtq_set_token_trace(self._engine, None)
+            self._launch_checked(device, launch)
         return q, None
 
     def forward_pairwise(self, patches, pos, scales):
@@ -397,17 +444,14 @@ class VTAMIQ(nn.Module):
         if use_scales and (scales is None or any(t is None for t in scales)):
             raise ValueError("Model uses scale embedding but scales is passed as None.")
         with torch.cuda.device(device):
-            lib = self._ensure_engine(device)
             pt = [self._prep(t, device) for t in patches]
             ps = [self._prep(t, device) for t in pos]
             sc = [self._prep(t, device) for t in scales] if use_scales else None
             q = torch.empty(2 * B, device=device, dtype=torch.float32)
             arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.vtq_forward_pairwise(self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N,
-                                                q.data_ptr(), stream))
-        if self.validate_inputs:
-            self.check_inputs()
+            self._launch_checked(device, lambda lib: _lib.check(lib.vtq_forward_pairwise(
+                self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N, q.data_ptr(), stream)))
         return q[:B], q[B:]
 
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------
