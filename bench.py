@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-pairs/sec of the VTAMIQ ViT-B/16 pair forward (P=500 patches) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--patches P] [--precision bf16x3|bf16|fp8w]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--patches P]
+                    [--precision fp16x3|fp16x2|fp16|bf16x3|bf16|fp8]      (default fp16x3, the mode that meets the 1e-3 tolerance)
 
 One process per GPU; every rank scores its own shard of the global batch (weak scaling: per-GPU batch fixed) and one RCCL
 all-gather of the scores closes each step.  Two ways to get the N ranks:
@@ -9,7 +10,10 @@ all-gather of the scores closes each step.  Two ways to get the N ranks:
   * `python bench.py --gpus N` on its own: the parent process starts the N ranks itself as child processes BEFORE it makes
     any GPU call (never an exec from a process that touched the GPU), forwards rank 0's JSON line and exits non-zero if
     any rank failed.
-Inputs are synthetic and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Inputs are synthetic and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.  Beside `value` (exactly K steps
+after W warm-up steps, as the driver asks) the line carries `sustained`: the same workload after >= 2 s of back-to-back forwards,
+timed over >= 3 s (the chip's clock under load settles over seconds), and `fidelity`: what every numerics mode does to
+SROCC / KROCC / PLCC / RMSE against the fp32 oracle's scores on a distortion ladder.
 """
 import argparse
 import json
@@ -44,6 +48,7 @@ def _free_port() -> int:
 def self_launch(n: int, argv, timeout_s: float) -> int:
     """Start n rank processes (this script, same argv) with the torch.distributed env contract, wait, forward rank 0's
     stdout.  The parent never imports torch or touches the GPU.  Children are stopped by PID if one fails or time runs out."""
+    import threading
     port = _free_port()
     procs = []
     for r in range(n):
@@ -51,9 +56,12 @@ def self_launch(n: int, argv, timeout_s: float) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    # rank 0's stdout is drained while it runs: a rank that prints more than the pipe holds must not block until the timeout
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.extend(iter(procs[0].stdout.readline, "")), daemon=True)
+    reader.start()
     deadline = time.time() + timeout_s
     rc = 0
-    out0 = ""
     try:
         pending = set(range(n))
         while pending:
@@ -61,8 +69,6 @@ def self_launch(n: int, argv, timeout_s: float) -> int:
                 code = procs[r].poll()
                 if code is not None:
                     pending.discard(r)
-                    if r == 0:
-                        out0 = procs[0].stdout.read()
                     if code != 0:
                         rc = rc or code or 1
                         print(f"[bench] rank {r} exited with code {code}", file=sys.stderr)
@@ -81,11 +87,8 @@ def self_launch(n: int, argv, timeout_s: float) -> int:
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
-    if not out0 and procs[0].stdout and not procs[0].stdout.closed:
-        try:
-            out0 = procs[0].stdout.read()
-        except Exception:
-            pass
+    reader.join(timeout=10)
+    out0 = "".join(chunks)
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if rc == 0 and len(lines) != 1:
         print(f"[bench] rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
@@ -105,11 +108,68 @@ def synth_inputs_on_device(torch, B, N, device, seed):
     return (ref, dist), (pos, pos.clone()), (None, None)
 
 
+LADDER_SIGMAS = (0.02, 0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5)
+
+
+def synth_ladder_on_device(torch, B, N, device, seed):
+    """The same generator with the distortion strength varied per pair: sigma = LADDER_SIGMAS[i % 8] of the noise (a ladder of
+    distortion levels, as an IQA test set has) -- the inputs of the `fidelity` block."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ref = torch.rand(B, N, 3, 16, 16, device=device, generator=g) * 2 - 1
+    sig = torch.tensor([LADDER_SIGMAS[i % len(LADDER_SIGMAS)] for i in range(B)], device=device).view(B, 1, 1, 1, 1)
+    dist = (ref + sig * torch.randn(ref.shape, device=device, generator=g)).clamp_(-1, 1)
+    pos = torch.rand(B, N, 2, device=device, generator=g).clamp_(max=1 - 1e-6)
+    return (ref, dist), (pos, pos.clone()), (None, None)
+
+
+def mode_fidelity(torch, make_model, spec, sd_np, modes, device, pairs=64, N=500, chunk=32, seed=777, threads=None):
+    """What the numerics modes cost in the reference's own metric (utils/misc/correlations.py:21-51): `pairs` synthetic pairs on a
+    distortion ladder, the fp32 oracle's scores on the host as the target, every mode's scores as the prediction, through
+    vtamiq_amd.validate.compute_correlations (the HIP rank / Kendall / Pearson kernels + the reference's logistic fit)."""
+    import numpy as np
+    from oracle import vtamiq_oracle as O
+    from vtamiq_amd.validate import compute_correlations
+    inp = synth_ladder_on_device(torch, pairs, N, device, seed)
+    if threads:
+        torch.set_num_threads(threads)
+    sd = O.to_torch(sd_np)
+    t0 = time.perf_counter()
+    q_ref = []
+    for i in range(0, pairs, 8):                             # the oracle in chunks of 8 pairs (memory of the attention matrices)
+        sl = slice(i, min(i + 8, pairs))
+        q_ref.append(O.vtamiq_forward(sd, spec, (inp[0][0][sl].cpu(), inp[0][1][sl].cpu()), (inp[1][0][sl].cpu(), inp[1][1][sl].cpu()),
+                                      (None, None))[0])
+    q_ref = torch.cat(q_ref)
+    cpu_s = time.perf_counter() - t0
+    ref_np = q_ref.double().numpy()
+    rms = float(np.sqrt(np.mean(ref_np ** 2)))
+    out = {"pairs": pairs, "patches": N, "ladder_sigmas": list(LADDER_SIGMAS), "target": "fp32 oracle scores (host)",
+           "oracle_seconds": cpu_s, "rms_q_ref": rms, "modes": {}}
+    q_dev = q_ref.to(device)
+    for prec in modes:
+        m = make_model(prec)
+        qs = []
+        with torch.no_grad():
+            for i in range(0, pairs, chunk):
+                sl = slice(i, min(i + chunk, pairs))
+                qs.append(m((inp[0][0][sl], inp[0][1][sl]), (inp[1][0][sl], inp[1][1][sl]), (None, None))[0])
+        q = torch.cat(qs)
+        c = compute_correlations(q_dev, q)
+        d = np.abs(q.double().cpu().numpy() - ref_np)
+        big = np.abs(ref_np) >= 0.1 * rms
+        out["modes"][prec] = {"SROCC": c["SROCC"], "KROCC": c["KROCC"], "PLCC": c["PLCC"], "RMSE": c["RMSE"],
+                              "PLCC_NOFIT": c["PLCC_NOFIT"], "RMSE_NOFIT": c["RMSE_NOFIT"],
+                              "max_rel_err_big_scores": float(np.max(d[big] / np.abs(ref_np[big]))), "max_abs_err_over_rms": float(d.max() / rms)}
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
 def fc1_traffic(precision, B):
     """HBM bytes of ONE full-batch fc1 GEMM from the committed PMC passes (profiles/*_gemm_fc1_traffic.json: FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs at B=32), scaled linearly with the batch.  A committed
     measurement of the same kernel, not a counter read during this run (rocprofv3 is not on bench.py's path)."""
-    for name in ("r02_gemm_fc1_traffic.json", "r01_gemm_fc1_traffic.json"):
+    for name in ("r03_gemm_fc1_traffic.json", "r02_gemm_fc1_traffic.json", "r01_gemm_fc1_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return d[precision]["bytes_per_launch"] * (B / 32.0), "profiles/" + name
@@ -255,6 +315,10 @@ def main():
     ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC passes instead of measuring it")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` block (>= 2 s warm-up + >= 3 s timed)")
+    ap.add_argument("--sustained-seconds", type=float, nargs=2, default=(2.0, 3.0), metavar=("WARM", "TIMED"))
+    ap.add_argument("--no-fidelity", action="store_true", help="skip the `fidelity` block (mode scores vs the fp32 oracle on a distortion ladder)")
+    ap.add_argument("--fidelity-pairs", type=int, default=64)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are stopped")
     # launcher self-test on CPU (tests/test_bench_launcher.py): gloo ranks + a stub model, no HIP anywhere
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
@@ -295,6 +359,8 @@ def main():
     global_batch = B * world
     inputs = synth_inputs_on_device(torch, B, N, device, 1234 + rank)
 
+    rank_times = []          # per-rank wall time of the last run() (all ranks hold all of them)
+
     def run(model, steps, warmup, inp=inputs, gb=global_batch, profile_class=None):
         with torch.no_grad():
             for _ in range(warmup):
@@ -318,8 +384,41 @@ def main():
                 model.profile_enable([])
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         if world > 1:
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_times[:] = [float(e.item()) for e in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            rank_times[:] = [dt]
         return float(t.item()), q, prof
+
+    def run_sustained(model, warm_s, timed_s, inp=inputs, profile_class=None):
+        """Back-to-back forwards (at most 3 in flight: the host never idles the GPU, the queue never grows) for warm_s seconds
+        untimed, then for >= timed_s seconds timed."""
+        def spin(seconds):
+            evs, n = [], 0
+            t_end = time.perf_counter() + seconds
+            t0 = time.perf_counter()
+            while time.perf_counter() < t_end:
+                model(*inp)
+                e = torch.cuda.Event()
+                e.record()
+                evs.append(e)
+                n += 1
+                if len(evs) > 3:
+                    evs.pop(0).synchronize()
+            sync()
+            return n, time.perf_counter() - t0
+        with torch.no_grad():
+            spin(warm_s)
+            if profile_class:
+                model.profile_enable([profile_class])
+            n, dt_s = spin(timed_s)
+            prof = None
+            if profile_class:
+                prof = model.profile_collect()[profile_class]
+                model.profile_enable([])
+        return n, dt_s, prof
 
     if a.stub:                                # launcher / collective plumbing only; never a measurement
         from tests.bench_stub import StubModel
@@ -353,6 +452,29 @@ def main():
     dt, q, prof = run(model, a.steps, a.warmup, profile_class=DOM)
     assert q.shape == (global_batch,) and bool(torch.isfinite(q).all())
     pairs_per_s = global_batch * a.steps / dt
+    headline_rank_times = list(rank_times)
+    allgather_us = None
+    if world > 1:                                 # the step's one collective, timed alone: a missed scaling target can be read off the record
+        qloc = torch.zeros(B, device=device)
+        for _ in range(10):
+            gather_scores(qloc, global_batch)
+        sync(); dist.barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            gather_scores(qloc, global_batch)
+        sync()
+        tg = torch.tensor([(time.perf_counter() - t0) / 100 * 1e6], device=device, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        allgather_us = float(tg.item())
+    sustained = None
+    if on_gpu and world == 1 and not a.no_sustained:
+        n_s, dt_s, prof_s = run_sustained(model, a.sustained_seconds[0], a.sustained_seconds[1], profile_class=DOM)
+        sustained = {"value": B * n_s / dt_s, "unit": "image-pairs/s", "forwards": n_s, "seconds": dt_s, "warmup_seconds": a.sustained_seconds[0],
+                     "ms_per_step": dt_s / n_s * 1e3,
+                     "note": "same workload and model as `value`; back-to-back forwards (<= 3 in flight) for warmup_seconds untimed, then timed"}
+        if prof_s and prof_s[1] > 0:
+            sustained["fc1_avg_launch_ms"] = prof_s[0] / prof_s[1]
+            sustained["fc1_launches"] = int(prof_s[1])
     f_pair = spec.flops_per_pair(N)                      # algorithmic (SURVEY 8d / BASELINE.md)
     pruned = os.environ.get("VTQ_NO_CLS_PRUNE", "0") != "1"
     # executed flops per pair, per mode: the CLS-only last layer is used by every mode but fp8 (there the CLS row must go through
@@ -369,6 +491,8 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if a.precision.startswith("fp16") else ("e4m3" if a.precision == "fp8" else "bf16"), "data": "synthetic",
         "rccl_ranks": rccl_ranks,
+        "rank_step_ms": {"min": min(headline_rank_times) / a.steps * 1e3, "max": max(headline_rank_times) / a.steps * 1e3},
+        "allgather_us": allgather_us,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
                                f"{N} patches of 16x16x3, random-init seeded weights",
                    "global_batch": global_batch, "patches": N, "seq_len": S, "parallelism": f"dp{world}",
@@ -390,7 +514,7 @@ def main():
 
     def roofline_of(prof_entry, steps, note):
         ms_sum, launches = prof_entry
-        full_layers = spec.num_layers - (1 if pruned else 0)       # fc1 GEMM launches per step = full layers x part-batches
+        full_layers = spec.num_layers - (1 if (pruned and a.precision != "fp8") else 0)       # fc1 GEMM launches per step (fp8 runs the full last layer)
         per_step = launches / steps
         flops_launch = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim * full_layers / per_step    # algorithmic, unpadded rows
         ach = flops_launch / (ms_sum / launches * 1e-3) / 1e12
@@ -409,6 +533,13 @@ def main():
                 "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
                 "flops_per_launch": flops_launch, "note": note}
 
+    if sustained:
+        sustained["forward_mfma_frac"] = mfma_frac(sustained["value"])
+        if "fc1_avg_launch_ms" in sustained:
+            fl = 2.0 * (2 * B * S) * spec.hidden_size * spec.mlp_dim
+            sustained["fc1_tflops"] = fl / (sustained["fc1_avg_launch_ms"] * 1e-3) / 1e12
+            sustained["fc1_roofline_frac"] = sustained["fc1_tflops"] / PEAK_BF16_TFLOPS
+        out["sustained"] = sustained
     if prof and prof[1] > 0:
         out["roofline"] = roofline_of(prof, a.steps, "HIP events recorded by the engine on the launch stream around every fc1 launch "
                                       "of the timed region of `value`")
@@ -463,12 +594,17 @@ def main():
                                                           "statement is tests/test_gpu_fp8.py against oracle/fp8_oracle.py")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, spec, sd_np)
+        if not a.no_fidelity and world == 1 and on_gpu:
+            # every mode's scores against the fp32 oracle in the reference's own metric (bounded sample; the full table on flat-init
+            # and trained-like weights is profiles/r03_mode_fidelity.txt, tools/mode_fidelity.py)
+            out["fidelity"] = mode_fidelity(torch, make_model, spec, sd_np, ["fp16x3", "bf16x3", "fp16x2", "fp16", "bf16", "fp8"], device,
+                                            pairs=a.fidelity_pairs, N=N, threads=min(effective_cores(), 64))
         if "roofline" in out and world == 1 and not a.no_live_traffic:
             # HBM-side bytes of the dominant kernel measured on THIS box now (the timed regions are over; the GPU is idle)
             tb, src = live_fc1_traffic(a.precision, B, S)
             committed = out["roofline"]["traffic"]
             if tb is not None:
-                full_layers = spec.num_layers - (1 if pruned else 0)
+                full_layers = spec.num_layers - (1 if (pruned and a.precision != "fp8") else 0)
                 out["roofline"]["traffic"] = tb * full_layers / out["roofline"]["launches_per_step"]
                 out["roofline"]["traffic_source"] = src
                 out["roofline"]["traffic_committed_pass"] = committed

@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The model raises FileNotFoundError, like the reference (transformer.py:622-624), when `pretrained` (default True) finds no ViT
+# checkpoint; the tests construct models with seeded weights and no checkpoint on disk, so they opt in to the documented escape
+# (tests/test_layout.py::test_missing_pretrained_checkpoint_raises checks the default behaviour with the variable removed).
+os.environ.setdefault("VTAMIQ_ALLOW_MISSING_WEIGHTS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

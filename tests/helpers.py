@@ -20,6 +20,7 @@ def load_case(name):
     """-> (golden npz dict, vtamiq kwargs, spec, numpy state dict, (patches, pos, scales) numpy)."""
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     kw = json.loads(str(g["kwargs"]))
+    kw.setdefault("vit_config", {})["pretrained"] = False      # as make_golden.build_reference did for the reference: seeded weights follow
     spec = make_spec(**json.loads(json.dumps(kw)))
     sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"])) if "stress_qk" in g else synth.make_state_dict(spec, int(g["wseed"]))
     patches, pos, scales = synth.make_inputs(spec, int(g["B"]), int(g["N"]), int(g["iseed"]),

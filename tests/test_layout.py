@@ -195,3 +195,21 @@ def test_abi_rejects_bad_arguments_without_touching_a_gpu():
     assert lib.vtq_reserve(None, 1, 1) != 0
     assert lib.vtq_workspace_bytes(None, 1, 1) == 0
     assert lib.vtq_k_gemm_schedule(256, 100, 768, 1, None, 0) == -1
+
+
+def test_missing_pretrained_checkpoint_raises(monkeypatch, tmp_path):
+    """pretrained=True (the reference's default, backbone.py:25) with no checkpoint file: FileNotFoundError like np.load in the
+    reference (transformer.py:622-624), not silently random weights; VTAMIQ_ALLOW_MISSING_WEIGHTS=1 is the explicit opt-out."""
+    import warnings
+    from vtamiq_amd import VTAMIQ
+    monkeypatch.delenv("VTAMIQ_ALLOW_MISSING_WEIGHTS", raising=False)
+    monkeypatch.delenv("VTAMIQ_VIT_WEIGHTS", raising=False)
+    missing = str(tmp_path / "nope.npz")
+    with pytest.raises(FileNotFoundError):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, vit_weights_path=missing))
+    VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, vit_weights_path=missing, pretrained=False))     # explicit: fine
+    monkeypatch.setenv("VTAMIQ_ALLOW_MISSING_WEIGHTS", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, vit_weights_path=missing))
+    assert any("does not exist" in str(x.message) for x in w)

@@ -13,8 +13,6 @@ ap.add_argument("--H", type=int, default=768)
 ap.add_argument("--fmt", nargs="+", default=["bf16", "bf16x3", "fp16", "fp16x3"])
 a = ap.parse_args()
 lib = _lib.load()
-diag = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
-is_diag = hasattr(lib, "vtq_debug_gemm_diag") and lib.vtq_debug_gemm_diag(diag.data_ptr(), 0)     # tools/_abl/diag.so: in-kernel phase stamps
 S_pad = a.S          # the engine packs sequences back to back
 rows = a.nseq * S_pad + 128
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -41,9 +39,3 @@ for fmt in a.fmt:
     ts.sort()
     fl = 4.0 * a.nseq * nh * a.S * a.S * 64
     print(f"attention {fmt} nseq={a.nseq} S={a.S} H={a.H}: {ts[3]*1e3:.1f} us  {fl/ts[3]/1e9:.1f} TF algorithmic  err {err:.1e}")
-    if is_diag:
-        diag.zero_(); call(); torch.cuda.synchronize()
-        d = diag[:8].cpu().double()
-        tiles = d[4].item()
-        print(f"    per 64-key tile and wave (cycles, stamps included): QK^T {d[0]/tiles:.0f}  softmax {d[1]/tiles:.0f}  PV {d[2]/tiles:.0f}  "
-              f"wait+barrier {d[3]/tiles:.0f}   main loop per wave {d[5]/d[6]:.0f} cycles over {tiles/d[6]:.1f} tiles")

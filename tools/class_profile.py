@@ -11,8 +11,8 @@ ap.add_argument("--refdefault", action="store_true")
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16", "fp8"])
 a = ap.parse_args()
 for prec in a.precision:
-    m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True),
-                                       ca_reduction=16) if a.refdefault else {}))
+    m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, pretrained=False),
+                                       ca_reduction=16) if a.refdefault else dict(vit_config=dict(variant="ViT-B16", pretrained=False))))
     sd = synth.make_state_dict(m.spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
     patches, pos, _ = synth.make_inputs(m.spec, a.batch, a.patches, 7)

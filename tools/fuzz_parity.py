@@ -26,7 +26,7 @@ for ci in range(a.cases):
         prec = a.precision
     tol = 1e-3 if prec == "fp16x3" else (2e-2 if prec == "fp16x2" else 5e-3)     # fp16x2: throughput mode, smoke bound only (8e-3 seen)
     pairwise = rng.random() < 0.3
-    kw = dict(vit_config=dict(variant=variant, num_keep_layers=L, num_extra_tokens=T, num_scales=scales, use_layer_scale=bool(T)),
+    kw = dict(vit_config=dict(variant=variant, num_keep_layers=L, num_extra_tokens=T, num_scales=scales, use_layer_scale=bool(T), pretrained=False),
               num_rgs=2, num_rcabs=2, calibrate=bool(rng.random() < 0.8), diff_scale=bool(rng.random() < 0.8))
     m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
     sd = synth.make_state_dict(m.spec, 100 + ci)

@@ -12,9 +12,9 @@ ap.add_argument("--patches", type=int, default=1024); ap.add_argument("--scales"
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--refdefault", action="store_true", help="the reference's default topology (train_config.py:169-194): 6 layers, 8 register tokens, LayerScale, r = 16")
 a = ap.parse_args()
-kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales))
+kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales, pretrained=False))
 if a.refdefault:
-    kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales), ca_reduction=16)
+    kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales, pretrained=False), ca_reduction=16)
 for prec in ("fp16x3", "fp16x2", "fp16", "bf16", "fp8"):
     m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
     spec = m.spec

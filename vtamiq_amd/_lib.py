@@ -19,7 +19,7 @@ PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16
 NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33}
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
-MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 3)}
+MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
 ABI_VERSION = 3
 
 KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]

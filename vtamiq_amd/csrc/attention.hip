@@ -23,14 +23,7 @@
 #include "kernels.h"
 
 namespace vtq {
-unsigned long long* g_attn_diag = nullptr;      // diagnostic builds (-DVTQ_GEMM_DIAG) only: set through gemm_set_diag
 namespace {
-
-#ifdef VTQ_GEMM_DIAG
-#define VTQ_AT_STAMP(acc) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); acc += t_ - dg_last; dg_last = t_; }
-#else
-#define VTQ_AT_STAMP(acc)
-#endif
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -42,26 +35,17 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 template <typename T>
 __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x8& hi, typename Vec<T>::x8& lo) {
     if constexpr (std::is_same<T, f16>::value) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
         uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            hw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]));   // truncation: hi <= p, p - hi exact in fp32
-        // lo = RNE(p - hi) by v_fma_mixlo / mixhi_f16 (fma(p, 1.0, -hi), hi read from its f16 half): 8 instructions for the 8
-        // values instead of 8 conversions back + 8 subtractions + 4 packs.  The softmax is bound by vector-instruction issue.
-        // Hazards hipcc does not pad inside / in front of an asm statement: (1) a v_exp result may not be read by the very next
-        // vector instruction (trans forwarding): every p[] reaches this statement through the v_cvt_pkrtz above, whose result
-        // the statement also consumes, so each v_exp is at least two instructions back; (2) the two halves of one destination
-        // are written four instructions apart (partial-register write, then read-modify-write of the same register).
-        asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(lw[0]), "=&v"(lw[1]), "=&v"(lw[2]), "=&v"(lw[3])
-            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(hw[0]), "v"(hw[1]), "v"(hw[2]), "v"(hw[3]));
+        for (int j = 0; j < 4; ++j) {
+            const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]);      // truncation: hi <= p, p - hi exact in fp32
+            const h2 hh = __builtin_bit_cast(h2, hp);
+            hw[j] = __builtin_bit_cast(uint32_t, hp);
+            // plain C++ (v_cvt_f32_f16 + v_sub): an inline-asm v_fma_mix here read v_exp results inside the hardware's
+            // trans -> VALU forwarding window, which hipcc does not pad for asm operands: rare wrong lo halves (measured)
+            lw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p[2 * j] - (float)hh[0], p[2 * j + 1] - (float)hh[1]));
+        }
         typedef __attribute__((ext_vector_type(4))) uint32_t u4;
         hi = __builtin_bit_cast(f16x8, u4{hw[0], hw[1], hw[2], hw[3]});
         lo = __builtin_bit_cast(f16x8, u4{lw[0], lw[1], lw[2], lw[3]});
@@ -78,8 +62,7 @@ __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x
 
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out,
-                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale, int stagger,
-                                                        unsigned long long* diag) {
+                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale) {
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
@@ -99,14 +82,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     {
         const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7, idx = wid >> 3;
         wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
-    // Two workgroups share a CU (one wave each per SIMD).  Dispatched together they run in lockstep -- both in their MFMA phase,
-    // then both in their softmax phase -- and the SIMD's matrix pipe and its vector issue are used one after the other.  The second
-    // workgroup of every CU (blocks 256..511 of the launch under the observed round-robin placement: a speed matter only) starts
-    // `stagger` x 1024 cycles late, about half a tile period, so that one's softmax runs beside the other's MFMAs; the offset
-    // persists (a workgroup that ends is replaced at its own tile boundary).
-    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const int qb = wid % nqb;
     const int head = (wid / nqb) % nh;
@@ -166,11 +141,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-#ifdef VTQ_GEMM_DIAG
-    unsigned long long dg_qk = 0, dg_sm = 0, dg_pv = 0, dg_bar = 0, dg_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_last) :: "memory");
-    const unsigned long long dg_begin = dg_last;
-#endif
     for (int t = 0; t < nt; ++t) {
         const int nxt = cur ^ 1;
         if (t + 1 < nt) stage(t + 1, nxt);
@@ -195,11 +165,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             }
         }
 
-#ifdef VTQ_GEMM_DIAG
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(sacc[kb]));      // the QK^T MFMAs have retired when the stamp is taken
-#endif
-        VTQ_AT_STAMP(dg_qk)
         // ---- online softmax (base-2 domain; scale folded into one FMA per score) -----------------------------------
         if ((t + 1) * KT > S) {                 // wave-uniform: only the last tile(s) hold padded keys
 #pragma unroll
@@ -237,11 +202,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         }
         m_run = m_new;
         l_run += rs;
-#ifdef VTQ_GEMM_DIAG
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(sacc[kb]));
-#endif
-        VTQ_AT_STAMP(dg_sm)
 
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q] -------------------------------------------------------------
 #pragma unroll
@@ -277,22 +237,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                 }
             }
 
-#ifdef VTQ_GEMM_DIAG
-#pragma unroll
-        for (int d = 0; d < 2; ++d) asm volatile("" : "+v"(o_acc[d]));
-#endif
-        VTQ_AT_STAMP(dg_pv)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 has landed
         __syncthreads();
-        VTQ_AT_STAMP(dg_bar)
         cur = nxt;
     }
-#ifdef VTQ_GEMM_DIAG
-    if (diag && lane == 0) {
-        atomicAdd(diag + 0, dg_qk); atomicAdd(diag + 1, dg_sm); atomicAdd(diag + 2, dg_pv); atomicAdd(diag + 3, dg_bar);
-        atomicAdd(diag + 4, (unsigned long long)nt); atomicAdd(diag + 5, dg_last - dg_begin); atomicAdd(diag + 6, 1ull);
-    }
-#endif
 
     // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -345,8 +293,7 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
         }
     }
     const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
-    static const int stagger = [] { const char* v = getenv("VTQ_ATTN_STAGGER"); return v ? atoi(v) : 0; }();     // measurement knob for now
-    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale, stagger, g_attn_diag);
+    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale);
     return hipGetLastError();
 }
 

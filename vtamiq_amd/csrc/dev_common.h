@@ -83,33 +83,6 @@ __device__ __forceinline__ void split2(float v, T& hi, T& lo) {
     lo = (T)(v - (float)hi);
 }
 
-// The same split for FOUR values of the f16 format in 6 vector instructions instead of 14: two v_cvt_pk_f16_f32 for the hi pairs
-// (RNE, like the cast), and lo = RNE(v - hi) by v_fma_mixlo/mixhi_f16 -- fma(v, 1.0, -hi) with hi read straight from its f16
-// half, computed in fp32 and rounded once into the low / high half of the destination: bit for bit what split2 gives
-// (tools/micro/mix_probe.hip checks that on the device, ties and subnormals included).  The epilogues and the attention
-// softmax are bound by vector-instruction ISSUE (one per ~4-5 cycles per SIMD for its two waves together, measured with
-// in-kernel stamps: profiles/r03_gemm_epilogue_stamps.txt), so instructions saved there are time saved.
-// The two halves of one destination are written by instructions two apart (partial-register write followed by a read of the
-// same register needs a wait state on gfx950: LLVM's dst-sel forwarding hazard; inside an asm statement nothing is padded).
-// The inputs must not come straight from a transcendental (v_exp ...): its result may not be read by the next vector
-// instruction (trans forwarding hazard) and hipcc pads nothing for asm operands -- callers pass values that went through
-// an ordinary VALU instruction, or make the statement depend on one that did (`after`).
-__device__ __forceinline__ void split4_f16(const float (&v)[4], f16x4& hi, f16x4& lo) {
-    // the hi conversions sit inside the statement too: left to hipcc, the cast is contracted with the multiply-add that
-    // produced v (v_fma_mixlo_f16 on the unrounded product) -- the double-rounding trap described at split2
-    uint32_t h0, h1, l0, l1;
-    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
-        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-    typedef __attribute__((ext_vector_type(2))) uint32_t u2;
-    hi = __builtin_bit_cast(f16x4, u2{h0, h1});
-    lo = __builtin_bit_cast(f16x4, u2{l0, l1});
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -776,6 +776,16 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(e, B, N, nimg);
     const int H = e->H, T = e->T;
+    {   // tile schedules of this geometry's GEMM shapes: built and uploaded here (first forward of a shape only), not inside a launch
+        const int wpl = e->wpl, M = (int)g.M_pad;
+        HIP_TRY(gemm_prepare((int)g.P_pad, H, (int)e->PDp, wpl, s));
+        HIP_TRY(gemm_prepare(M, 3 * H, H, wpl, s));
+        HIP_TRY(gemm_prepare(M, 2 * H, H, wpl, s));
+        HIP_TRY(gemm_prepare(M, H, H, wpl, s));
+        HIP_TRY(gemm_prepare(M, e->Mdim, H, wpl, s));
+        HIP_TRY(gemm_prepare(M, H, e->Mdim, wpl, s));
+        if (c.num_adapters > 0) { HIP_TRY(gemm_prepare(M, (int)e->Hqp, H, wpl, s)); HIP_TRY(gemm_prepare(M, H, (int)e->Hqp, wpl, s)); }
+    }
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {

@@ -208,10 +208,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                             }
                             if constexpr (NP == 1) {
                                 h = tx4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                            } else if constexpr (std::is_same<T, f16>::value) {
-                                tx4 l;
-                                split4_f16(v, h, l);           // 6 vector instructions for the four values (dev_common.h)
-                                lo[li] = l;
                             } else {
                                 tx4 l;
 #pragma unroll
@@ -829,9 +825,10 @@ int column_group(int ntn, int K, int wpl) {
 // Device-resident schedules, per DEVICE (a second engine on another GPU of the same process gets its own copies) and per
 // (tile grid, column group); entries are a few KiB and live until exit.
 struct DevSched { int* dev; int nwg; };
-hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds) {
+hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds, hipStream_t s) {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int, int>, DevSched> cache;
+    static std::vector<std::vector<int>*> staged;              // host images of uploads in flight on some stream: kept for the process lifetime
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -839,18 +836,27 @@ hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds) {
     const auto key = std::make_tuple(dev, ntm, ntn, cg, (int)dynamic);
     auto it = cache.find(key);
     if (it != cache.end()) { ds = it->second; return hipSuccess; }
-    const std::vector<int> h = dynamic ? build_schedule_dynamic(ntm, ntn, cg) : build_schedule(ntm, ntn, cg);
-    DevSched d{nullptr, dynamic ? h[0] - 1 : kXcds * cus_per_xcd()};
-    e = hipMalloc(&d.dev, h.size() * sizeof(int));
-    if (e != hipSuccess) return e;
-    e = hipMemcpy(d.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);     // blocking; first launch of a shape only
-    if (e != hipSuccess) return e;
+    // First use of a shape on this device.  The engine does this from vtq_reserve / the top of vtq_forward (gemm_prepare), never
+    // between the launches of a forward; the per-kernel test entry points may land here from a launch.  The upload is an async
+    // copy on the launch stream (ordered before the kernel that reads it) from a host image that stays alive.
+    std::vector<int>* h = new std::vector<int>(dynamic ? build_schedule_dynamic(ntm, ntn, cg) : build_schedule(ntm, ntn, cg));
+    DevSched d{nullptr, dynamic ? (*h)[0] - 1 : kXcds * cus_per_xcd()};
+    e = hipMalloc(&d.dev, h->size() * sizeof(int));
+    if (e != hipSuccess) { delete h; return e; }
+    e = hipMemcpyAsync(d.dev, h->data(), h->size() * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { (void)hipFree(d.dev); delete h; return e; }
+    staged.push_back(h);
     cache[key] = d;
     ds = d;
     return hipSuccess;
 }
 
-unsigned long long* g_diag_buf = nullptr;
+int env_cg() {
+    static const int v = [] { const char* c = getenv("VTQ_GEMM_CG"); return c ? atoi(c) : 0; }();    // measurement knob: column-group width of the tile order
+    return v;
+}
+
+unsigned long long* g_diag_buf = nullptr;      // diagnostic builds: stamp buffer and shadow-VALU count (gemm_set_diag)
 int g_diag_shadow = 0;
 
 int env_flags() {
@@ -877,9 +883,8 @@ template <typename T, int TERMS, int EPI> hipError_t launch_t(GemmArgs a, hipStr
     constexpr int WPL = (TERMS == 3) ? 2 : 1;
     DevSched ds;
     a.flags = env_flags();
-    int cg = column_group(a.N / 256, a.K, WPL);
-    if (const char* v = getenv("VTQ_GEMM_CG")) cg = atoi(v);           // measurement knob: column-group width of the tile order
-    e = schedule_for(a.M / 256, a.N / 256, cg, (a.flags & GEMM_FLAG_DYNAMIC) != 0, ds);
+    const int cg = env_cg() > 0 ? env_cg() : column_group(a.N / 256, a.K, WPL);
+    e = schedule_for(a.M / 256, a.N / 256, cg, (a.flags & GEMM_FLAG_DYNAMIC) != 0, ds, s);
     if (e != hipSuccess) return e;
     a.sched = ds.dev;
     a.diag = g_diag_buf;
@@ -900,14 +905,20 @@ template <typename T, int TERMS> hipError_t launch_e(const GemmArgs& a, int epil
 
 }  // namespace
 
-extern unsigned long long* g_attn_diag;        // attention.hip: diagnostic builds sum their phase stamps into the first words of the same buffer
-void gemm_set_diag(unsigned long long* buf, int shadow) { g_diag_buf = buf; g_diag_shadow = shadow; g_attn_diag = buf; }
+void gemm_set_diag(unsigned long long* buf, int shadow) { g_diag_buf = buf; g_diag_shadow = shadow; }
 bool gemm_is_diag_build() {
 #ifdef VTQ_GEMM_DIAG
     return true;
 #else
     return false;
 #endif
+}
+
+hipError_t gemm_prepare(int M, int N, int K, int wpl, hipStream_t s) {
+    if (M <= 0 || M % 256 || N <= 0 || N % 256) return hipErrorInvalidValue;
+    DevSched ds;
+    const int cg = env_cg() > 0 ? env_cg() : column_group(N / 256, K, wpl);
+    return schedule_for(M / 256, N / 256, cg, (env_flags() & GEMM_FLAG_DYNAMIC) != 0, ds, s);
 }
 
 std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {

@@ -67,6 +67,9 @@ hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
 void gemm_set_diag(unsigned long long* buf, int shadow);
 bool gemm_is_diag_build();
+// Build and upload (async on s) the persistent tile schedule of an (M, N, K) GEMM with wpl weight planes on the current device, if
+// it is not cached yet: called by the engine before the first launch of a forward so that launch_gemm itself never allocates
+hipError_t gemm_prepare(int M, int N, int K, int wpl, hipStream_t s);
 // Persistent schedule of a (ntm x ntn)-tile GEMM with K columns and wpl weight planes (host only): 257 offsets, then the
 // per-workgroup lists; entry = (tile << 2) | kind, kind 0 full, 1 / 2 top / bottom 128-row half
 std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
