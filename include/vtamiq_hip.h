@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 3
+#define VTQ_ABI_VERSION 4
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -36,7 +36,7 @@ extern "C" {
                             /* attention (QK^T, PV): the 3-term fp16 form                                                      */
 #define VTQ_PREC_FP8    5   /* BASELINE configs[4]: linear layers on OCP e4m3 operands with the MX-scaled MFMA (unit block      */
                             /* scales, 2x the bf16 MFMA rate): weights e4m3 with per-output-channel power-of-two scales,         */
-                            /* activations e4m3 with static per-tensor scales; attention single fp16; head fp16 hi/lo.             */
+                            /* activations e4m3 with calibrated per-tensor scales (vtq_fp8_*); attention single fp16; head hi/lo.  */
                             /* Checked against the fake-quant oracle (oracle/fp8_oracle.py), NOT within 1e-3 of the fp32 model. */
 
 /* operand-format code of the per-kernel entry points: MFMAs per product (1 | 2 | 3) + 16 for fp16 planes (0 = bf16):
@@ -114,8 +114,23 @@ int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float
  * (transformer.py:417-421); vtq_forward clamps such an index into the table instead of gathering out of bounds and records it.
  * Bit 1: the CLS difference of some pair was not finite -- an operand left its format's range upstream (the fp16 operand modes
  * carry |v| <= 65504; VTQ_PREC_BF16X3 has the fp32 range), or the inputs / weights held inf / NaN.
+ * Bit 2 (VTQ_PREC_FP8): an activation times its scale exceeded e4m3's largest value and was clamped to +-448 (the scales no
+ * longer fit the data: calibrate again, vtq_fp8_calibrate).
  * This call synchronises `stream`, returns the flags accumulated since the last call and clears them. */
 int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
+
+/* VTQ_PREC_FP8: per-tensor power-of-two activation scales, one per quantisation point -- [0] the packed patches, then for every
+ * layer l: [1 + 4l] LayerNorm-1 output, [2 + 4l] attention context, [3 + 4l] LayerNorm-2 output, [4 + 4l] GELU output.
+ * An engine starts with static defaults (256, 8, 16, 8, 4) and CALIBRATES on the batch of its first vtq_forward: every producing
+ * kernel reports max |value|, the largest power of two mapping it to <= 224 becomes the scale, the producer is run again with
+ * it (one stream synchronisation per point, that forward only; its scores are computed with the final scales).  Environment
+ * VTQ_FP8_STATIC_SCALES=1 keeps the defaults.  vtq_fp8_calibrate repeats the calibration on a batch of the caller's choice
+ * (arguments as vtq_forward); get / set expose the 1 + 4 * num_layers values (get returns the count, -1 for a non-fp8 engine;
+ * set requires positive powers of two and marks the engine calibrated). */
+int  vtq_fp8_calibrate(vtq_handle h, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
+                       const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream);
+int  vtq_fp8_get_scales(vtq_handle h, float* out, int32_t cap);
+int  vtq_fp8_set_scales(vtq_handle h, const float* scales, int32_t n);
 
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors

@@ -59,3 +59,27 @@ def test_fp8_model_fixture_and_distance():
         d = gate_error(q, g["q"])
         print(f"\n[{name}] fp8 model vs fp32 model: {d:.3e}")
         assert 1e-4 < d < 2.0
+
+
+def test_pick_scale_and_calibrate():
+    """The calibration rule (engine.hip fp8_pick_scale): the largest power of two mapping max |value| to <= 224, exact at the
+    boundaries; `calibrate` yields scales under which nothing of the calibration batch is clamped."""
+    assert F8.pick_scale(224.0, 1.0) == 1.0 and F8.pick_scale(224.0001, 1.0) == 0.5 and F8.pick_scale(112.0, 1.0) == 2.0
+    assert F8.pick_scale(1.75, 1.0) == 128.0 and F8.pick_scale(1.7500001, 1.0) == 64.0 and F8.pick_scale(0.0, 8.0) == 8.0
+    assert F8.pick_scale(float("nan"), 4.0) == 4.0 and F8.pick_scale(3e-9, 1.0) == 2.0 ** 36
+    g, kw, spec, sd, (patches, pos, scales) = load_case("scales3_b2_n40")
+    p, ps, sc = split_inputs(patches, pos, scales)
+    s8 = F8.calibrate(O.to_torch(sd), spec, p, ps, sc)
+    assert len(s8.ln1) == spec.num_layers and s8.patch == F8.pick_scale(float(np.abs(patches).max()), 1.0)
+    seen = []
+
+    def pick(name, i, t):
+        seen.append(float(t.abs().max()) * getattr(s8, name)[i])
+    sdt = O.to_torch(sd)
+    x = F8.embeddings(sdt, spec, torch.cat(p), torch.cat(ps), torch.cat(sc), s8)
+    for i in range(spec.num_layers):
+        x = F8.encoder_layer(sdt, spec, i, x, s8, pick)
+    assert len(seen) == 4 * spec.num_layers and max(seen) <= F8.FP8_TARGET and min(seen) > F8.FP8_TARGET / 2.0 - 1e-3
+    q_cal = F8.vtamiq_forward(sdt, spec, p, ps, sc, s8=s8)[0]
+    q_static = F8.vtamiq_forward(sdt, spec, p, ps, sc)[0]
+    assert torch.isfinite(q_cal).all() and q_cal.shape == q_static.shape

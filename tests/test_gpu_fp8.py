@@ -208,36 +208,38 @@ def test_fp8_stages_teacher_forced(name):
     model = build(kw, sd)
     p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
     pr = Probe(model, (p, ps, sc), spec, int(g["B"]), int(g["N"]))
+    s8 = F8.Scales.from_engine(model.fp8_scales())          # calibrated on this batch by the first forward (engine.hip fp8_stage)
     sdt = O.to_torch(sd)
     H, Md, nh = spec.hidden_size, spec.mlp_dim, spec.num_heads
     dh = H // nh
     for layer in sorted({0, spec.num_layers // 2, spec.num_layers - 1}):
-        print(f"\n[{name}] layer {layer}")
+        S_LN1, S_ATT, S_LN2, S_GELU = s8.ln1[layer], s8.att[layer], s8.ln2[layer], s8.gelu[layer]
+        print(f"\n[{name}] layer {layer}   scales: LN1 x{S_LN1:g}  attention x{S_ATT:g}  LN2 x{S_LN2:g}  GELU x{S_GELU:g}")
         pre = f"transformer.encoder.layers.{layer}."
         st = [pr.grab(layer, k) for k in range(7)]
         R = st[0]["R"]
         x0 = pr.seqs(st[0]["x"])                                                    # LayerNorm 1 leaves the stream untouched
         ln1 = pr.e4(st[0]["ln"], H, R)
-        check_bytes("LayerNorm 1", ln1, O._layer_norm(x0, sdt[pre + "attention_norm.weight"], sdt[pre + "attention_norm.bias"]) * F8.S_LN, 3e-3)
+        check_bytes("LayerNorm 1", ln1, O._layer_norm(x0, sdt[pre + "attention_norm.weight"], sdt[pre + "attention_norm.bias"]) * S_LN1, 3e-3)
         qkv = pr.seqs(st[1]["big"][:R * 3 * H * 2].view(torch.float16).float().view(R, 3 * H))
-        want = torch.cat([F8.linear8(ln1.double(), F8.S_LN, sdt[f"{pre}attn.{n}.weight"].double(), sdt[f"{pre}attn.{n}.bias"].double())
+        want = torch.cat([F8.linear8(ln1.double(), S_LN1, sdt[f"{pre}attn.{n}.weight"].double(), sdt[f"{pre}attn.{n}.bias"].double())
                           for n in ("query", "key", "value")], -1)
         check_f32("QKV (fp16)", qkv.double(), want, 1e-3)
         q, k, v = (t.double().view(pr.nseq, pr.S, nh, dh).permute(0, 2, 1, 3) for t in qkv.split(H, -1))
         ctx = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v).permute(0, 2, 1, 3).reshape(pr.nseq, pr.S, H)
         ctx8 = pr.e4(st[2]["ln"], H, R)
-        check_bytes("attention", ctx8, ctx.float() * F8.S_ATT, 5e-2)                # single-fp16 P and V: 3e-4 of noise against a 6 % grid
-        h = F8.linear8(ctx8.double(), F8.S_ATT, sdt[pre + "attn.out.weight"].double(), sdt[pre + "attn.out.bias"].double())
+        check_bytes("attention", ctx8, ctx.float() * S_ATT, 5e-2)                # single-fp16 P and V: 3e-4 of noise against a 6 % grid
+        h = F8.linear8(ctx8.double(), S_ATT, sdt[pre + "attn.out.weight"].double(), sdt[pre + "attn.out.bias"].double())
         if spec.use_layer_scale:
             h = h * sdt[pre + "ls1.gamma"].double()
         x1 = pr.seqs(st[3]["x"])
         check_f32("x + attn", x1.double(), x0.double() + h, 1e-4)
         ln2 = pr.e4(st[4]["ln"], H, R)
-        check_bytes("LayerNorm 2", ln2, O._layer_norm(x1, sdt[pre + "ffn_norm.weight"], sdt[pre + "ffn_norm.bias"]) * F8.S_LN, 3e-3)
-        pre_act = F8.linear8(ln2.double(), F8.S_LN, sdt[pre + "ffn.fc1.weight"].double(), sdt[pre + "ffn.fc1.bias"].double())
+        check_bytes("LayerNorm 2", ln2, O._layer_norm(x1, sdt[pre + "ffn_norm.weight"], sdt[pre + "ffn_norm.bias"]) * S_LN2, 3e-3)
+        pre_act = F8.linear8(ln2.double(), S_LN2, sdt[pre + "ffn.fc1.weight"].double(), sdt[pre + "ffn.fc1.bias"].double())
         g8 = pr.e4(st[5]["big"], Md, R)
-        check_bytes("fc1 + GELU", g8, (Fn.gelu(pre_act) * F8.S_GELU).float(), 3e-3)
-        h = F8.linear8(g8.double(), F8.S_GELU, sdt[pre + "ffn.fc2.weight"].double(), sdt[pre + "ffn.fc2.bias"].double())
+        check_bytes("fc1 + GELU", g8, (Fn.gelu(pre_act) * S_GELU).float(), 3e-3)
+        h = F8.linear8(g8.double(), S_GELU, sdt[pre + "ffn.fc2.weight"].double(), sdt[pre + "ffn.fc2.bias"].double())
         if spec.use_layer_scale:
             h = h * sdt[pre + "ls2.gamma"].double()
         check_f32("x + mlp", pr.seqs(st[6]["x"]).double(), x1.double() + h, 1e-4)
@@ -252,7 +254,8 @@ def test_fp8_patch_embedding_teacher_forced():
     x = pr.seqs(pr.grab(0, 0)["x"])
     sdt = O.to_torch(sd)
     pc, psc, scc = split_inputs(patches, pos, scales)
-    want = torch.cat([F8.embeddings(sdt, spec, pc[i], psc[i], scc[i]) for i in range(2)])
+    s8 = F8.Scales.from_engine(model.fp8_scales())
+    want = torch.cat([F8.embeddings(sdt, spec, pc[i], psc[i], scc[i], s8) for i in range(2)])
     check_f32("embeddings", x, want, 1e-4)
 
 
@@ -279,7 +282,8 @@ def test_fp8_end_to_end_noise_level(name):
     assert aux is None and q.shape == (B,) and np.isfinite(q).all()
     pc, psc, scc = split_inputs(patches, pos, scales)
     tr8, tr32 = {}, {}
-    q8 = F8.vtamiq_forward(O.to_torch(sd), spec, pc, psc, scc, trace=tr8)[0].numpy()
+    s8 = F8.Scales.from_engine(model.fp8_scales())          # the engine's calibrated scales (first forward = this batch)
+    q8 = F8.vtamiq_forward(O.to_torch(sd), spec, pc, psc, scc, trace=tr8, s8=s8)[0].numpy()
     O.vtamiq_forward(O.to_torch(sd), spec, pc, psc, scc, trace=tr32)
     t32 = torch.cat([tr32["tokens_ref"], tr32["tokens_dist"]], dim=1).numpy()
     got, t8 = trace.cpu().numpy(), tr8["tokens"].numpy()
@@ -294,8 +298,67 @@ def test_fp8_end_to_end_noise_level(name):
     assert np.abs(got[0] - t8[0]).max() <= 1e-6 * np.abs(t8[0]).max()
 
 
+def _flat(s8):
+    return [s8.patch] + [v for i in range(len(s8.ln1)) for v in (s8.ln1[i], s8.att[i], s8.ln2[i], s8.gelu[i])]
+
+
+@pytest.mark.parametrize("name", ["c1_b2_n50", "scales3_b2_n40"])
+def test_fp8_calibration_matches_the_oracles(name):
+    """The scales the engine calibrates on its first batch against oracle.fp8_oracle.calibrate on the same batch: the same power
+    of two at (nearly) every quantisation point -- the maxima the two see differ by rounding noise, so a point whose maximum sits
+    on a power-of-two boundary of the rule may land one binade apart, never more."""
+    import math
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    model = build(kw, sd)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    with torch.no_grad():
+        q = model(p, ps, sc)[0]
+    model.check_inputs()                                      # nothing clamped with calibrated scales
+    got = _flat(F8.Scales.from_engine(model.fp8_scales()))
+    want = _flat(F8.calibrate(O.to_torch(sd), spec, *split_inputs(patches, pos, scales)))
+    assert len(got) == len(want) == 1 + 4 * spec.num_layers
+    ratio = [abs(math.log2(a / b)) for a, b in zip(got, want)]
+    print(f"\n[{name}] engine scales {got}\n oracle scales {want}")
+    assert max(ratio) <= 1.0 and sum(r == 0 for r in ratio) >= 0.85 * len(ratio)
+    assert all(math.frexp(v)[0] == 0.5 for v in got)          # powers of two
+    # explicit scales round-trip through the ABI, and a second forward is bit-identical (the scales are model state, not batch state)
+    model.set_fp8_scales(model.fp8_scales())
+    with torch.no_grad():
+        assert torch.equal(model(p, ps, sc)[0], q)
+
+
+def test_fp8_static_scales_saturate_on_trained_like_weights_calibrated_ones_do_not(monkeypatch):
+    """tests.helpers.stress_state (LayerNorm gains x8 on outlier channels, fc2 bias +2): the round-2 constants (LayerNorm x8, GELU x4)
+    push values past e4m3's 448 -- clamped, and now REPORTED (error word bit 2) -- while scales calibrated on the batch do not."""
+    from tests.helpers import stress_state
+    from vtamiq_amd import synth
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=4, pretrained=False))
+    spec = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8").spec
+    sd = stress_state(spec, 9, qk=5.0, outlier=64.0)
+    patches, pos, scales = synth.make_inputs(spec, 2, 80, 21)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    monkeypatch.setenv("VTQ_FP8_STATIC_SCALES", "1")
+    m_static = build(kw, sd)
+    with torch.no_grad():
+        q_static = m_static(p, ps, sc)[0]
+    with pytest.raises(FloatingPointError, match="clamped"):
+        m_static.check_inputs()
+    monkeypatch.delenv("VTQ_FP8_STATIC_SCALES")
+    m_cal = build(kw, sd)
+    with torch.no_grad():
+        q_cal = m_cal(p, ps, sc)[0]
+    m_cal.check_inputs()                                      # no flag
+    s8 = m_cal.fp8_scales()
+    assert min(s8["ln1"] + s8["ln2"]) < 8.0                   # calibration had to lower a LayerNorm scale below the constant
+    q32 = O.vtamiq_forward(O.to_torch(sd), spec, *split_inputs(patches, pos, scales))[0].numpy()
+    e_static, e_cal = gate_error(q_static.cpu().numpy(), q32), gate_error(q_cal.cpu().numpy(), q32)
+    print(f"\nstressed weights, fp8 vs fp32 oracle: static scales {e_static:.3e} (saturated), calibrated {e_cal:.3e}")
+    assert np.isfinite(q_cal.cpu().numpy()).all()
+
+
 def test_fp8_batch_invariance_and_order():
-    """Each pair's score is independent of its neighbours in the batch (static scales: nothing is batch-dependent)."""
+    """Each pair's score is independent of its neighbours in the batch (the scales are calibrated once, on the first batch, and are
+    model state from then on: nothing is batch-dependent)."""
     g, kw, spec, sd, (patches, pos, scales) = load_case("c2shape_b4_n500")
     model = build(kw, sd)
     p, ps, sc = split_inputs(patches, pos, scales, device=DEV)

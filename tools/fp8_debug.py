@@ -2,6 +2,7 @@
 """Stage-by-stage comparison of the engine's fp8 mode with the fake-quant oracle on layer `--layer` of a golden case (GPU box).
 Uses the test hooks vtq_debug_stop_after / vtq_debug_buffers."""
 import argparse, ctypes as C, json, math, os, sys
+os.environ["VTQ_FP8_STATIC_SCALES"] = "1"      # this walk-through uses the oracle's static scales (F8.S_*): keep the engine on them too
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import torch.nn.functional as F

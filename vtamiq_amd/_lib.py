@@ -20,7 +20,7 @@ NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
 MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]
 
@@ -55,6 +55,9 @@ SIGNATURES = {
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "vtq_fp8_calibrate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_fp8_get_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "vtq_fp8_set_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "vtq_k_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

@@ -62,7 +62,7 @@ __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x
 
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out,
-                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale) {
+                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale, Fp8Obs obs) {
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    float amax8 = 0.f;                      // fp8 mode: max |context value| of this lane's real rows (kernels.h Fp8Obs)
     if (q_row < S_pad) {
         T* o = out + (row0 + q_row) * H + head * 64;
 #pragma unroll
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
                 if (out8_scale > 0.f) {          // fp8 mode: the out-proj GEMM reads e4m3 bytes
+                    if (q_row < S) amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
                     *(uint32_t*)((uint8_t*)out + (row0 + q_row) * H + head * 64 + dcol) =
                         pack_fp8x4(v[0] * out8_scale, v[1] * out8_scale, v[2] * out8_scale, v[3] * out8_scale);
                 } else if constexpr (NSPLIT == 1) {
@@ -270,13 +272,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                 }
             }
     }
+    if (out8_scale > 0.f) fp8_report(obs, amax8, out8_scale);
 }
 
 }  // namespace
 
 template <typename T, int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
-                              float out8_scale) {
+                              float out8_scale, Fp8Obs obs) {
     constexpr int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2);
     static std::mutex mu;
     static bool configured[64] = {false};          // hipFuncSetAttribute is per device
@@ -293,19 +296,19 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
         }
     }
     const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
-    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale);
+    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale, obs);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            Num num, hipStream_t s, float out8_scale) {
+                            Num num, hipStream_t s, float out8_scale, Fp8Obs obs) {
     if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (num.terms != 1 && num.terms != 3) || num.f16 > 1) return hipErrorInvalidValue;
     if (!num.f16) {
-        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale);
-        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale);
+        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
+        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
     }
-    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale);
-    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale);
+    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
+    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
 }
 
 }  // namespace vtq

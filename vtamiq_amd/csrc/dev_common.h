@@ -53,6 +53,11 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
     return (uint32_t)p;
 }
 
+// max |.| of four values folded into a running maximum (NaNs are ignored by v_max)
+__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+}
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
@@ -114,4 +119,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 #define VTQ_WAVE 64
+
+#ifdef __HIPCC__
+// End of an fp8 producer (kernels.h Fp8Obs): m = this lane's max |value| before scaling.  One atomic per wave, and only when asked.
+template <typename Obs>
+__device__ __forceinline__ void fp8_report(const Obs& o, float m, float scale) {
+    if (!o.amax && !o.err) return;                       // kernel argument: wave-uniform
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (o.amax) atomicMax((int*)o.amax, __float_as_int(m));
+        if (o.err && m * scale > 448.0f) atomicOr(o.err, 4);
+    }
+}
+#endif
 

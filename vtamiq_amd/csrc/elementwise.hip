@@ -29,11 +29,14 @@ __device__ __forceinline__ void store4(T* dst, int64_t plane, float a, float b, 
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t plane,
-                                                    int64_t n4, float scale) {
+                                                    int64_t n4, float scale, Fp8Obs obs) {
+    float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = ((const float4*)src)[i];
+        if constexpr (std::is_same<T, f8>::value) m = amax4(m, v.x, v.y, v.z, v.w);
         store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w, scale);
     }
+    if constexpr (std::is_same<T, f8>::value) fp8_report(obs, m, scale);
 }
 
 // rows of K floats -> rows of Kp >= K elements, zero beyond K (a weight whose K is padded to the GEMM's K-tile: ViT-B/8's 192-wide
@@ -83,7 +86,8 @@ struct ImgPtrs { const float* p[3]; };
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg, T* __restrict__ dst, int64_t plane, int BN, int K4,
-                                                           int Kp4, int64_t total4, float scale) {
+                                                           int Kp4, int64_t total4, float scale, Fp8Obs obs) {
+    float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / Kp4;                    // destination rows are Kp4 >= K4 quads wide, zero beyond K4
         const int c4 = (int)(i - row * Kp4);
@@ -93,8 +97,10 @@ __global__ __launch_bounds__(256) void pack_patches_kernel(ImgPtrs src, int nimg
             const float* sp = img == 0 ? src.p[0] : (img == 1 ? src.p[1] : src.p[2]);
             v = ((const float4*)sp)[(row - (int64_t)img * BN) * K4 + c4];
         }
+        if constexpr (std::is_same<T, f8>::value) m = amax4(m, v.x, v.y, v.z, v.w);
         store4<T, NPL>(dst + i * 4, plane, v.x, v.y, v.z, v.w, scale);
     }
+    if constexpr (std::is_same<T, f8>::value) fp8_report(obs, m, scale);
 }
 
 // UvPosEmbedding.forward index (transformer.py:417-421): floor(pos*G) -> i0*G + i1 + 1, evaluated in fp32 like torch;
@@ -197,7 +203,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
 template <int V4, typename T, int NPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ out, int64_t o_plane,
-                                                        int rows, float scale) {
+                                                        int rows, float scale, Fp8Obs obs) {
     constexpr int H = 256 * V4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -207,6 +213,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     T* o = out + (int64_t)row * H;
 #pragma unroll
     for (int i = 0; i < V4; ++i) store4<T, NPL>(o + (i * 64 + lane) * 4, o_plane, y[i].x, y[i].y, y[i].z, y[i].w, scale);
+    if constexpr (std::is_same<T, f8>::value) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) m = amax4(m, y[i].x, y[i].y, y[i].z, y[i].w);
+        fp8_report(obs, m, scale);
+    }
 }
 
 // encoder_norm on the two CLS rows of pair b only (transformer.py:376 applies it to all rows; only token 0 is
@@ -272,24 +284,24 @@ hipError_t launch_split_rows_pad(const float* src, void* dst, int64_t plane, int
     return hipGetLastError();
 }
 
-hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s, float scale) {
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s, float scale, Fp8Obs obs) {
     if (numel % 4) return hipErrorInvalidValue;
     const int64_t n4 = numel / 4;
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((split_kernel<TT, NP>), dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (TT*)dst, plane, n4, scale)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((split_kernel<TT, NP>), dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (TT*)dst, plane, n4, scale, obs)
     VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     return hipGetLastError();
 }
 
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16_,
-                               int planes, hipStream_t s, float scale, int Kp) {
+                               int planes, hipStream_t s, float scale, int Kp, Fp8Obs obs) {
     if (Kp == 0) Kp = K;
     if (K % 4 || Kp % 4 || Kp < K) return hipErrorInvalidValue;
     const int K4 = K / 4, Kp4 = Kp / 4;
     const int64_t total4 = (int64_t)rows_pad * Kp4;
     ImgPtrs ip{{imgs[0], imgs[1], nimg > 2 ? imgs[2] : nullptr}};
 #define VTQ_CALL(TT, NP) \
-    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, Kp4, total4, scale)
+    hipLaunchKernelGGL((pack_patches_kernel<TT, NP>), dim3(grid_for(total4, 256)), dim3(256), 0, s, ip, nimg, (TT*)dst, plane, BN, K4, Kp4, total4, scale, obs)
     VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     return hipGetLastError();
@@ -324,14 +336,14 @@ hipError_t launch_copy_tokens(const float* x, float* dst, int nseq, SeqMap sm, i
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int f16_, int planes, hipStream_t s, float scale) {
+                            int f16_, int planes, hipStream_t s, float scale, Fp8Obs obs) {
     const dim3 g((rows + 3) / 4), blk(256);
     if (H == 768) {
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<3, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<3, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale, obs)
         VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     } else if (H == 1024) {
-#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<4, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale)
+#define VTQ_CALL(TT, NP) hipLaunchKernelGGL((layernorm_kernel<4, TT, NP>), g, blk, 0, s, x, w, b, (TT*)out, o_plane, rows, scale, obs)
         VTQ_FMT_DISPATCH(f16_, planes, VTQ_CALL);
 #undef VTQ_CALL
     } else return hipErrorInvalidValue;

@@ -6,6 +6,7 @@
 // (the reference runs two serial passes with the same weights, vtamiq.py:100-101).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -41,10 +42,17 @@ int fail(const char* fmt, ...) {
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// fp8 mode: static power-of-two activation scales (value * scale is rounded to e4m3, |.| clamped to 448); oracle/fp8_oracle.py
-// carries the same constants.  patches in [-1, 1]; LayerNorm outputs up to ~sqrt(H) * |weight|; attention outputs are convex
-// combinations of V rows; GELU outputs follow the fc1 range.
+// fp8 mode: per-tensor power-of-two activation scales (value * scale is rounded to e4m3, |.| clamped to 448), one per
+// quantisation point: the packed patches, and per layer the LayerNorm-1 output, the attention context, the LayerNorm-2 output and
+// the GELU output.  They start at the round-2 constants below (oracle/fp8_oracle.py STATIC carries the same) and are replaced by
+// CALIBRATED ones: the first forward of an engine (or vtq_fp8_calibrate on a batch of the caller's choice) measures max |value| at
+// every point on that batch -- each producing kernel reports it (kernels.h Fp8Obs) and is run again once its scale is chosen, so
+// everything downstream already sees the final operands -- and takes the largest power of two that maps it to <= 224 (a factor two
+// of headroom for other batches; e4m3 is a floating format, so headroom costs no precision until values underflow 2^-9).
+// VTQ_FP8_STATIC_SCALES=1 keeps the constants.  A value that still exceeds 448 after scaling is clamped and raises bit 2 of the
+// error word (vtq_input_errors).
 constexpr float kSPatch = 256.0f, kSLn = 8.0f, kSAtt = 16.0f, kSGelu = 4.0f;
+constexpr float kFp8Target = 224.0f;
 
 struct Slot {
     void* dst = nullptr;      // destination (fp32 copy) or bf16 hi plane (split)
@@ -83,6 +91,10 @@ struct vtq_engine {
     int f16 = 0, apl = 1, wpl = 1;     // element type of every plane; planes per activation / per weight tensor
     int dbg_stop = -1;                 // tests: leave the encoder after stage layer * 7 + k (vtq_debug_stop_after), -1 = never
     bool fp8 = false;                  // linear layers on e4m3 operands (MX-scaled MFMA, unit block scales): VTQ_PREC_FP8
+    float s_patch = kSPatch;           //   activation scales (see kSPatch ...): patches, then per layer {LN1, attention, LN2, GELU}
+    std::vector<float> s_ln1, s_att, s_ln2, s_gelu;
+    bool fp8_static = false, fp8_calibrated = false, calibrating = false;
+    float* amax_slot = nullptr;        //   device word the producers report max |value| into during a calibration forward
     float* spatch = nullptr;           //   inverse weight scales of the patch embedding
     int64_t PDp = 0;                   // patch_dim rounded up to the GEMM's K granule (row pitch of the packed patches / weight)
     int64_t Hqp = 0;                   // adapters: H / 4 rounded up to the GEMM tile (N of the down projection, K of the up projection)
@@ -400,6 +412,29 @@ struct Prof {
 };
 
 
+// largest power of two s with m * s <= kFp8Target (exact: frexp, no log); 0 / non-finite m: keep `keep`
+float fp8_pick_scale(float m, float keep) {
+    if (!(m > 0.0f) || !std::isfinite(m)) return keep;
+    int ex = 0;
+    const float f = frexpf(m, &ex);                      // m = f * 2^ex, f in [0.5, 1);  224 = 0.875 * 2^8
+    return ldexpf(1.0f, (f <= 0.875f ? 8 : 7) - ex);
+}
+
+// One fp8 producer stage (a kernel that writes e4m3 activation bytes with scale `sc`).  Normal forwards: run it once, saturation
+// reported into the error word.  Calibration forward: run it reporting max |value|, read that (the one place a forward
+// synchronises), choose `sc`, run it again with the final scale.  launch(scale, obs) must be idempotent.
+template <typename F>
+int fp8_stage(vtq_engine* e, hipStream_t s, float& sc, F launch) {
+    if (!e->calibrating) return launch(sc, Fp8Obs{nullptr, e->err_flag});
+    HIP_TRY(hipMemsetAsync(e->amax_slot, 0, 4, s));
+    if (launch(sc, Fp8Obs{e->amax_slot, nullptr})) return 1;
+    float m = 0.f;
+    HIP_TRY(hipMemcpyAsync(&m, e->amax_slot, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    sc = fp8_pick_scale(m, sc);
+    return launch(sc, Fp8Obs{nullptr, e->err_flag});
+}
+
 // All encoder layers for the g.nseq sequences, enqueued on s.
 int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     const vtq_config& c = e->cfg;
@@ -481,25 +516,35 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             return launch_gemm(u, lin, EPI_RESID, s);
         };
         const int lnf = f8m ? 2 : f16, lnp = f8m ? 1 : apl;
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
+        {
+            Prof p(e, s, VTQ_K_LN);
+            if (f8m) {
+                if (fp8_stage(e, s, e->s_ln1[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, 2, 1, s, sc, ob)); return 0; })) return 1;
+            } else HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, lnf, lnp, s));
+        }
         if (e->dbg_stop == i * 7 + 0) return 0;
         {
             Prof p(e, s, VTQ_K_QKV);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wqkv; a.w_plane = Ly.pqkv;
             a.M = M; a.N = 3 * H; a.K = H; a.bias = Ly.bqkv; a.out = big; a.o_plane = e->big_plane; a.ldo = 3 * H;
-            a.wscale = Ly.sqkv; a.ascale_inv = 1.0f / kSLn;
+            a.wscale = Ly.sqkv; a.ascale_inv = 1.0f / e->s_ln1[i];
             HIP_TRY(launch_gemm(a, lin, EPI_BIAS, s));
         }
         if (e->dbg_stop == i * 7 + 1) return 0;
-        { Prof p(e, s, VTQ_K_ATTN); HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, f8m ? kSAtt : 0.0f)); }
+        {
+            Prof p(e, s, VTQ_K_ATTN);
+            if (f8m) {
+                if (fp8_stage(e, s, e->s_att[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, sc, ob)); return 0; })) return 1;
+            } else HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s));
+        }
         if (e->dbg_stop == i * 7 + 2) return 0;
         {
             Prof p(e, s, VTQ_K_OUTPROJ);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.wo; a.w_plane = Ly.po;
             a.M = M; a.N = H; a.K = H; a.bias = Ly.bo;
-            a.wscale = Ly.so; a.ascale_inv = 1.0f / kSAtt;
+            a.wscale = Ly.so; a.ascale_inv = 1.0f / e->s_att[i];
             if (adapters) {                      // the branch output h itself, as operand planes for the adapter (QKV is consumed: `big` is free)
                 GemmArgs hplanes = a;
                 hplanes.out = big; hplanes.o_plane = e->big_plane; hplanes.ldo = H;
@@ -510,15 +555,22 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             if (adapters) HIP_TRY(adapter_site(Ly, 0, big, e->big_plane, lnb, e->ln_plane, Ly.g1));   // x += ls1 * (up(gelu(down(h))) )
         }
         if (e->dbg_stop == i * 7 + 3) return 0;
-        { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, lnf, lnp, s, f8m ? kSLn : 1.0f)); }
+        {
+            Prof p(e, s, VTQ_K_LN);
+            if (f8m) {
+                if (fp8_stage(e, s, e->s_ln2[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, 2, 1, s, sc, ob)); return 0; })) return 1;
+            } else HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, lnf, lnp, s));
+        }
         if (e->dbg_stop == i * 7 + 4) return 0;
         {
             Prof p(e, s, VTQ_K_FC1);
             GemmArgs a{};
             a.A = lnb; a.a_plane = e->ln_plane; a.lda = H; a.W = Ly.w1; a.w_plane = Ly.p1;
             a.M = M; a.N = Md; a.K = H; a.bias = Ly.b1; a.out = big; a.o_plane = e->big_plane; a.ldo = Md;
-            a.wscale = Ly.s1; a.ascale_inv = 1.0f / kSLn; a.out_scale = kSGelu;
-            HIP_TRY(launch_gemm(a, lin, EPI_BIAS_GELU, s));
+            a.wscale = Ly.s1; a.ascale_inv = 1.0f / e->s_ln2[i];
+            if (f8m) {
+                if (fp8_stage(e, s, e->s_gelu[i], [&](float sc, Fp8Obs ob) { GemmArgs b = a; b.out_scale = sc; b.obs = ob; HIP_TRY(launch_gemm(b, lin, EPI_BIAS_GELU, s)); return 0; })) return 1;
+            } else HIP_TRY(launch_gemm(a, lin, EPI_BIAS_GELU, s));
         }
         if (e->dbg_stop == i * 7 + 5) return 0;
         {
@@ -526,7 +578,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             GemmArgs a{};
             a.A = big; a.a_plane = e->big_plane; a.lda = Md; a.W = Ly.w2; a.w_plane = Ly.p2;
             a.M = M; a.N = H; a.K = Md; a.bias = Ly.b2;
-            a.wscale = Ly.s2; a.ascale_inv = 1.0f / kSGelu;
+            a.wscale = Ly.s2; a.ascale_inv = 1.0f / e->s_gelu[i];
             if (adapters) {                      // LayerNorm 2's planes are consumed: the branch output goes to `lnbuf`
                 GemmArgs hplanes = a;
                 hplanes.out = lnb; hplanes.o_plane = e->ln_plane; hplanes.ldo = H;
@@ -659,11 +711,14 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
     { const char* np = getenv("VTQ_NO_CLS_PRUNE"); e->cls_prune = !(np && np[0] == '1'); }
+    e->s_ln1.assign(c.num_layers, kSLn); e->s_att.assign(c.num_layers, kSAtt); e->s_ln2.assign(c.num_layers, kSLn); e->s_gelu.assign(c.num_layers, kSGelu);
+    { const char* st = getenv("VTQ_FP8_STATIC_SCALES"); e->fp8_static = st && st[0] == '1'; }
     if (hipMalloc((void**)&e->err_flag, 16) != hipSuccess || hipMemset(e->err_flag, 0, 16) != hipSuccess) {
         vtq_destroy(e);
         return fail("vtq_create: device allocation failed");
     }
     e->allocs.push_back(e->err_flag);
+    e->amax_slot = (float*)(e->err_flag + 2);           // same 16-byte allocation
     if (build(e)) { vtq_destroy(e); return 1; }
     *out = e;
     return 0;
@@ -772,6 +827,10 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     for (auto& kv : e->slots)
         if (!kv.second.loaded) return fail("vtq_forward: weight '%s' was never loaded", kv.first.c_str());
     if (reserve(e, (nimg * B + 1) / 2, N)) return 1;       // capacity is kept in units of sequence pairs
+    // fp8 mode: the first forward of an engine calibrates the activation scales on its own batch (see kSPatch); it synchronises
+    // the stream once per quantisation point and returns this batch's scores computed with the final scales
+    struct CalibGuard { vtq_engine* e; ~CalibGuard() { e->calibrating = false; } } calib_guard{e};
+    if (e->fp8 && !e->fp8_static && !e->fp8_calibrated && e->dbg_stop < 0) e->calibrating = true;
     const int ndist = nimg - 1, HB = ndist * B;            // head batch
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(e, B, N, nimg);
@@ -790,8 +849,9 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
     {
         Prof p(e, s, VTQ_K_CONVERT);
-        if (e->fp8) HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, 2, 1, s, kSPatch, (int)e->PDp));
-        else HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s, 1.0f, (int)e->PDp));
+        if (e->fp8) {
+            if (fp8_stage(e, s, e->s_patch, [&](float sc, Fp8Obs ob) { HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, 2, 1, s, sc, (int)e->PDp, ob)); return 0; })) return 1;
+        } else HIP_TRY(launch_pack_patches(patches, nimg, e->big, e->big_plane, B * N, c.patch_dim, (int)g.P_pad, e->f16, e->apl, s, 1.0f, (int)e->PDp));
         HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
                                    c.pos_grid, c.num_scales, e->err_flag, s));
         HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
@@ -806,7 +866,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         a.bias = e->bpatch; a.x = e->x;
         a.row_map = e->row_map; a.idx1 = e->pidx; a.table1 = e->pos_table;
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
-        a.wscale = e->spatch; a.ascale_inv = 1.0f / kSPatch;
+        a.wscale = e->spatch; a.ascale_inv = 1.0f / e->s_patch;
         HIP_TRY(launch_gemm(a, e->lin, EPI_EMBED, s));
     }
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
@@ -834,6 +894,44 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s, e->err_flag));
         if (run_head(e, d, HB, q_out, s, true)) return 1;
     }
+    if (e->calibrating) e->fp8_calibrated = true;
+    return 0;
+}
+
+int vtq_fp8_calibrate(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
+                      const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
+    if (!e || !e->fp8) return fail("vtq_fp8_calibrate: not an fp8 engine");
+    e->fp8_calibrated = false;
+    const bool was_static = e->fp8_static;
+    e->fp8_static = false;
+    const int rc = vtq_forward(e, patches_ref, patches_dist, pos_ref, pos_dist, scales_ref, scales_dist, B, N, q_out, stream);
+    e->fp8_static = was_static;
+    return rc;
+}
+
+int vtq_fp8_get_scales(vtq_handle e, float* out, int32_t cap) {
+    if (!e || !e->fp8) return -1;
+    const int L = e->cfg.num_layers, n = 1 + 4 * L;
+    if (out) {
+        std::vector<float> v(n);
+        v[0] = e->s_patch;
+        for (int i = 0; i < L; ++i) { v[1 + 4 * i] = e->s_ln1[i]; v[2 + 4 * i] = e->s_att[i]; v[3 + 4 * i] = e->s_ln2[i]; v[4 + 4 * i] = e->s_gelu[i]; }
+        for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+    }
+    return n;
+}
+
+int vtq_fp8_set_scales(vtq_handle e, const float* in, int32_t n) {
+    if (!e || !e->fp8 || !in) return fail("vtq_fp8_set_scales: not an fp8 engine / null argument");
+    const int L = e->cfg.num_layers;
+    if (n != 1 + 4 * L) return fail("vtq_fp8_set_scales: %d values, expected %d (patches, then LN1 / attention / LN2 / GELU per layer)", n, 1 + 4 * L);
+    for (int i = 0; i < n; ++i) {
+        int ex = 0;
+        if (!(in[i] > 0.0f) || !std::isfinite(in[i]) || frexpf(in[i], &ex) != 0.5f) return fail("vtq_fp8_set_scales: scale %d = %g is not a positive power of two", i, in[i]);
+    }
+    e->s_patch = in[0];
+    for (int i = 0; i < L; ++i) { e->s_ln1[i] = in[1 + 4 * i]; e->s_att[i] = in[2 + 4 * i]; e->s_ln2[i] = in[3 + 4 * i]; e->s_gelu[i] = in[4 + 4 * i]; }
+    e->fp8_calibrated = true;
     return 0;
 }
 

@@ -136,6 +136,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         constexpr int RS = 272;                         // 256 B + 16 B pad
         constexpr int IMG = 64 * RS;
         constexpr int NPASS = MH * 2;
+        float amax8 = 0.f;                              // max |GELU output| of this lane before scaling (kernels.h Fp8Obs)
         auto convert = [&](int pass) {
             const int mh = pass >> 1, q = pass & 1;
             char* img = smem + STG + (pass & 1) * IMG;
@@ -154,6 +155,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
                         }
+                        amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
                         *(uint32_t*)(img + lrow * RS + col) = pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
                     }
         };
@@ -178,6 +180,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             interval_end();
         }
         copy_out(NPASS - 1);
+        fp8_report(p.obs, amax8, p.out_scale);
     } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // chunk (mh, q): the 64 rows {mh*128 + wr*64 + (2q + e)*16 + fr}, image row = wr*32 + e*16 + fr; one pass per plane
         constexpr int RS = 528;                         // 256 x 16 bit + 16 B pad: rows stay 16-B aligned for ds_read_b128

@@ -42,6 +42,12 @@ __host__ __device__ inline int64_t seq_row(const SeqMap& m, int s) { return (int
 // slope != NULL); p == NULL: none.
 struct PlaneOut { void* p; int64_t plane; int ld; int f16; int planes; const float* slope; };
 
+// fp8 mode: what a kernel that WRITES e4m3 activation bytes reports besides them (both optional):
+//   amax: running maximum of |value| BEFORE scaling, as float bits (atomicMax on the int view: values are >= 0) -- the calibration
+//         forward reads it to choose the tensor's power-of-two scale;
+//   err:  the engine's error word; bit 2 is set when a value * scale left e4m3's range and was clamped to +-448.
+struct Fp8Obs { float* amax; int* err; };
+
 struct GemmArgs {
     const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
     const void* W; int64_t w_plane;               // bf16 planes [N, K]
@@ -56,6 +62,7 @@ struct GemmArgs {
     // fp8 operands only: acc is de-scaled by wscale[n] * ascale_inv before the bias (per-output-channel weight scale, static
     // activation scale); a GELU output is written as e4m3(value * out_scale); a BIAS output as fp16 hi/lo planes
     const float* wscale; float ascale_inv; float out_scale;
+    Fp8Obs obs;                                   // fp8 GELU form only (the one GEMM epilogue that writes e4m3 bytes)
     const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
     int flags;                                    // set by launch_gemm: GEMM_FLAG_*
     // diagnostic builds (-DVTQ_GEMM_DIAG, tools/build_abl.sh) only; set by launch_gemm from gemm_set_diag, never read otherwise:
@@ -76,7 +83,8 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
 
 // fp32 -> 16-bit planes (f16: 0 = bf16, 1 = fp16; planes: 1 = single, 2 = hi + lo with lo `plane` elements behind hi), or
 // f16 == 2: e4m3 bytes of value * scale
-hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s, float scale = 1.0f);
+hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s, float scale = 1.0f,
+                        Fp8Obs obs = Fp8Obs{nullptr, nullptr});
 // fp8 weights: W[N][K] fp32 -> e4m3 rows with a per-row power-of-two scale; inv_scale[n] = 1 / scale
 hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s, int Kp = 0);
 // rows of K floats -> planes with row pitch Kp >= K, zero beyond K
@@ -84,7 +92,7 @@ hipError_t launch_split_rows_pad(const float* src, void* dst, int64_t plane, int
 
 // nimg images (ref, dist[, dist2]) of fp32 patches [B*N, K] each -> 16-bit planes [rows_pad, K], rows >= nimg*B*N zero-filled
 hipError_t launch_pack_patches(const float* const* imgs, int nimg, void* dst, int64_t plane, int BN, int K, int rows_pad, int f16,
-                               int planes, hipStream_t s, float scale = 1.0f, int Kp = 0);
+                               int planes, hipStream_t s, float scale = 1.0f, int Kp = 0, Fp8Obs obs = Fp8Obs{nullptr, nullptr});
 
 // per patch row r in [0, rows_pad): pos index, scale index (sc == nullptr: none), destination row in the residual stream (or -1);
 // positions outside [0, 1) are clamped into the table and flagged in *err (bit 0)
@@ -96,12 +104,12 @@ hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, con
                          int T, int H, hipStream_t s);
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int rows, int H,
-                            int f16, int planes, hipStream_t s, float scale = 1.0f);
+                            int f16, int planes, hipStream_t s, float scale = 1.0f, Fp8Obs obs = Fp8Obs{nullptr, nullptr});
 
 // num.terms: 1 = single planes, 3 = hi/lo planes for Q, K, V and P (the 2-term form is not offered: DESIGN.md section 2)
 // out8_scale > 0: the output is written as e4m3 bytes of value * out8_scale ([rows][H] bytes) instead of planes (fp8 mode)
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            Num num, hipStream_t s, float out8_scale = 0.0f);
+                            Num num, hipStream_t s, float out8_scale = 0.0f, Fp8Obs obs = Fp8Obs{nullptr, nullptr});
 
 // zero the rows of the residual stream that belong to no token: per-sequence pads, per-part tails, and everything up to rows_total
 hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s);

@@ -285,6 +285,9 @@ class VTAMIQ(nn.Module):
             _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
         if flags.value & 1:
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
+        if flags.value & 4:
+            raise FloatingPointError("fp8 mode: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
+                                     "calibrated scales do not fit this data; calibrate_fp8() on a representative batch")
         if flags.value & 2:
             raise FloatingPointError(
                 f"non-finite encoder output in precision={self.engine_precision!r}: an activation or weight left the operand format's range "
@@ -453,6 +456,47 @@ class VTAMIQ(nn.Module):
             self._launch_checked(device, lambda lib: _lib.check(lib.vtq_forward_pairwise(
                 self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N, q.data_ptr(), stream)))
         return q[:B], q[B:]
+
+    # ---- fp8 mode: activation scales ----------------------------------------------------------------------------
+    def fp8_scales(self):
+        """The engine's per-tensor activation scales of the fp8 mode: {"patch": s, "ln1": [L], "att": [L], "ln2": [L], "gelu": [L]}
+        (powers of two).  They are calibrated on the batch of the first forward (include/vtamiq_hip.h vtq_fp8_*);
+        calibrate_fp8() repeats that on a batch of your choice, set_fp8_scales() installs given ones."""
+        if self._engine is None or self.engine_precision != "fp8":
+            raise RuntimeError("fp8_scales: no fp8 engine yet (run a forward first)")
+        lib = _lib.load()
+        n = lib.vtq_fp8_get_scales(self._engine, None, 0)
+        buf = (C.c_float * n)()
+        lib.vtq_fp8_get_scales(self._engine, buf, n)
+        v = list(buf)
+        L = (n - 1) // 4
+        return {"patch": v[0], "ln1": v[1::4][:L], "att": v[2::4][:L], "ln2": v[3::4][:L], "gelu": v[4::4][:L]}
+
+    def set_fp8_scales(self, sc):
+        L = len(sc["ln1"])
+        flat = [sc["patch"]]
+        for i in range(L):
+            flat += [sc["ln1"][i], sc["att"][i], sc["ln2"][i], sc["gelu"][i]]
+        buf = (C.c_float * len(flat))(*flat)
+        _lib.check(_lib.load().vtq_fp8_set_scales(self._engine, buf, len(flat)))
+
+    def calibrate_fp8(self, patches, pos, scales):
+        """Re-calibrate the fp8 activation scales on this batch (arguments as forward()); returns the batch's scores."""
+        if self.precision != "fp8":
+            raise RuntimeError("calibrate_fp8: precision is not 'fp8'")
+        device = patches[0].device
+        use_scales = self.spec.use_scale_embedding
+        with torch.cuda.device(device):
+            lib = self._ensure_engine(device)
+            t = [self._prep(x, device) for x in (patches[0], patches[1], pos[0], pos[1])]
+            sc = [self._prep(x, device) for x in scales] if use_scales else [None, None]
+            B, N = patches[0].shape[:2]
+            q = torch.empty(B, device=device, dtype=torch.float32)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.vtq_fp8_calibrate(self._engine, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                             sc[0].data_ptr() if use_scales else None, sc[1].data_ptr() if use_scales else None,
+                                             B, N, q.data_ptr(), stream))
+        return q
 
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------
     def profile_enable(self, classes):
