@@ -184,12 +184,17 @@ def grid_step(v):
     return torch.maximum(torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -6))) - 3), torch.tensor(2.0 ** -9))
 
 
-def check_bytes(name, got, want_unrounded, max_flips):
-    """got: the engine's e4m3 values; want_unrounded: the oracle's scaled value before rounding."""
+def check_bytes(name, got, want_unrounded, max_flips, noise=2e-5):
+    """got: the engine's e4m3 values; want_unrounded: the oracle's scaled value before rounding.  A byte may sit on the neighbouring
+    grid point (the two sides' inputs differ by arithmetic noise), never further -- where "further" allows for that noise itself,
+    `noise` x the tensor's max: with calibrated scales the tensor's max maps to 112 .. 224, so the fp16 noise of the attention
+    (3e-4 of the max) is many steps of the SUBNORMAL grid (2^-9) for elements near zero, while still far below a grid step of any
+    element that matters."""
     want = F8.to_e4m3(want_unrounded)
     flips = (got != want).float().mean().item()
-    worst = ((got - want).abs() / grid_step(want_unrounded)).max().item()
-    print(f"   {name:12s} bytes off the oracle's rounding: {flips:.2e}   worst {worst:.2f} grid steps")
+    slack = noise * want_unrounded.abs().max()
+    worst = (((got - want).abs() - slack).clamp_min(0) / grid_step(want_unrounded)).max().item()
+    print(f"   {name:12s} bytes off the oracle's rounding: {flips:.2e}   worst {worst:.2f} grid steps beyond the noise allowance")
     assert flips < max_flips, (name, flips)
     assert worst <= 1.0 + 1e-6, (name, worst)               # never more than the neighbouring grid point
 
@@ -228,7 +233,7 @@ def test_fp8_stages_teacher_forced(name):
         q, k, v = (t.double().view(pr.nseq, pr.S, nh, dh).permute(0, 2, 1, 3) for t in qkv.split(H, -1))
         ctx = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v).permute(0, 2, 1, 3).reshape(pr.nseq, pr.S, H)
         ctx8 = pr.e4(st[2]["ln"], H, R)
-        check_bytes("attention", ctx8, ctx.float() * S_ATT, 5e-2)                # single-fp16 P and V: 3e-4 of noise against a 6 % grid
+        check_bytes("attention", ctx8, ctx.float() * S_ATT, 5e-2, noise=1e-3)                # single-fp16 P and V: 3e-4 of noise against a 6 % grid
         h = F8.linear8(ctx8.double(), S_ATT, sdt[pre + "attn.out.weight"].double(), sdt[pre + "attn.out.bias"].double())
         if spec.use_layer_scale:
             h = h * sdt[pre + "ls1.gamma"].double()
@@ -238,7 +243,7 @@ def test_fp8_stages_teacher_forced(name):
         check_bytes("LayerNorm 2", ln2, O._layer_norm(x1, sdt[pre + "ffn_norm.weight"], sdt[pre + "ffn_norm.bias"]) * S_LN2, 3e-3)
         pre_act = F8.linear8(ln2.double(), S_LN2, sdt[pre + "ffn.fc1.weight"].double(), sdt[pre + "ffn.fc1.bias"].double())
         g8 = pr.e4(st[5]["big"], Md, R)
-        check_bytes("fc1 + GELU", g8, (Fn.gelu(pre_act) * S_GELU).float(), 3e-3)
+        check_bytes("fc1 + GELU", g8, (Fn.gelu(pre_act) * S_GELU).float(), 3e-3, noise=5e-5)
         h = F8.linear8(g8.double(), S_GELU, sdt[pre + "ffn.fc2.weight"].double(), sdt[pre + "ffn.fc2.bias"].double())
         if spec.use_layer_scale:
             h = h * sdt[pre + "ls2.gamma"].double()

@@ -101,12 +101,12 @@ def load() -> C.CDLL:
     except OSError as e:
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
-        if name.startswith("vtq_debug_") and os.environ.get("VTQ_LIB_PATH") and not hasattr(lib, name):
-            continue                     # an A/B build of an older tree (tools/_abl) may predate a debug hook; the shipped library may not
+        if os.environ.get("VTQ_LIB_PATH") and not hasattr(lib, name):
+            continue                     # an A/B build of an older tree (tools/_abl, VTQ_LIB_PATH) may predate an entry point; the shipped library may not
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.vtq_abi_version() != ABI_VERSION:
+    if lib.vtq_abi_version() != ABI_VERSION and not os.environ.get("VTQ_LIB_PATH"):
         raise RuntimeError("libvtamiq_hip.so ABI version mismatch")
     _lib = lib
     return lib

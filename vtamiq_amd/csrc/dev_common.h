@@ -118,6 +118,75 @@ __device__ __forceinline__ float gelu_erf(float x) {
 #endif
 }
 
+// gelu_erf on FOUR values, the same operations in the same order (bit-identical results), as one hand-ordered instruction block:
+// the four polynomial chains advance in lock step, so every instruction's operand was produced four instructions earlier (no
+// dependent-issue stall, no s_nop behind the v_exp: hipcc, left alone, either serialises the chains -- one element at a time with
+// an s_nop after every v_exp -- or packs pairs into v_pk_*_f32, which issue slower than what they replace), and the clamp / max
+// are single instructions on the raw MFMA accumulators (as C++ fminf / fmaxf they each get a canonicalising v_max in front).
+// 11 instructions per value.  The GEMM epilogue is bound by vector-instruction issue (profiles/r03_gemm_epilogue_stamps.txt).
+__device__ __forceinline__ void gelu_erf4(float (&x)[4]) {
+    float t0, t1, t2, t3, q0, q1, q2, q3;
+    const float c6 = -4.525732038018759e-06f, c57 = 5.7f;
+    asm("v_min_f32_e64 %0, |%8|, %13\n\tv_min_f32_e64 %1, |%9|, %13\n\tv_min_f32_e64 %2, |%10|, %13\n\tv_min_f32_e64 %3, |%11|, %13\n\t"
+        "v_fmaak_f32 %4, %12, %0, 0x37814f5e\n\tv_fmaak_f32 %5, %12, %1, 0x37814f5e\n\tv_fmaak_f32 %6, %12, %2, 0x37814f5e\n\tv_fmaak_f32 %7, %12, %3, 0x37814f5e\n\t"
+        "v_fmaak_f32 %4, %4, %0, 0x3a142202\n\tv_fmaak_f32 %5, %5, %1, 0x3a142202\n\tv_fmaak_f32 %6, %6, %2, 0x3a142202\n\tv_fmaak_f32 %7, %7, %3, 0x3a142202\n\t"
+        "v_fmaak_f32 %4, %4, %0, 0xbbfaa789\n\tv_fmaak_f32 %5, %5, %1, 0xbbfaa789\n\tv_fmaak_f32 %6, %6, %2, 0xbbfaa789\n\tv_fmaak_f32 %7, %7, %3, 0xbbfaa789\n\t"
+        "v_fmaak_f32 %4, %4, %0, 0x3d58c9b9\n\tv_fmaak_f32 %5, %5, %1, 0x3d58c9b9\n\tv_fmaak_f32 %6, %6, %2, 0x3d58c9b9\n\tv_fmaak_f32 %7, %7, %3, 0x3d58c9b9\n\t"
+        "v_fmaak_f32 %4, %4, %0, 0x3eeb092f\n\tv_fmaak_f32 %5, %5, %1, 0x3eeb092f\n\tv_fmaak_f32 %6, %6, %2, 0x3eeb092f\n\tv_fmaak_f32 %7, %7, %3, 0x3eeb092f\n\t"
+        "v_fmaak_f32 %4, %4, %0, 0x3f935811\n\tv_fmaak_f32 %5, %5, %1, 0x3f935811\n\tv_fmaak_f32 %6, %6, %2, 0x3f935811\n\tv_fmaak_f32 %7, %7, %3, 0x3f935811\n\t"
+        "v_fma_f32 %4, -%0, %4, -1.0\n\tv_fma_f32 %5, -%1, %5, -1.0\n\tv_fma_f32 %6, -%2, %6, -1.0\n\tv_fma_f32 %7, -%3, %7, -1.0\n\t"
+        "v_exp_f32_e32 %4, %4\n\tv_exp_f32_e32 %5, %5\n\tv_exp_f32_e32 %6, %6\n\tv_exp_f32_e32 %7, %7\n\t"
+        "v_max_f32_e32 %0, 0, %8\n\tv_max_f32_e32 %1, 0, %9\n\tv_max_f32_e32 %2, 0, %10\n\tv_max_f32_e32 %3, 0, %11\n\t"
+        "v_fma_f32 %4, -|%8|, %4, %0\n\tv_fma_f32 %5, -|%9|, %5, %1\n\tv_fma_f32 %6, -|%10|, %6, %2\n\tv_fma_f32 %7, -|%11|, %7, %3"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(c6), "s"(c57));       // c6 in a VGPR: an SGPR beside the literal would be two constant-bus operands
+    x[0] = q0; x[1] = q1; x[2] = q2; x[3] = q3;
+}
+
+// hi = RNE(v), lo = RNE(v - hi) for FOUR values of the f16 format in 6 instructions: two v_cvt_pk_f16_f32, then
+// lo = fma(v, 1.0, -hi) by v_fma_mixlo / mixhi_f16 with hi read from its f16 half (computed in fp32, rounded once) -- bit for bit
+// what split2 gives (tools/micro/mix_probe.hip: 0 mismatches on 4M values incl. ties and subnormals).  The conversions sit inside
+// the statement too: left to hipcc the cast is contracted with the multiply-add that produced v (the double-rounding trap
+// described at split2).  The two halves of one destination are written two instructions apart (partial-register write, then a
+// read-modify-write of the same register: gfx950 dst-sel forwarding hazard, nothing is padded inside an asm statement).
+__device__ __forceinline__ void split4_f16(const float (&v)[4], f16x4& hi, f16x4& lo) {
+    uint32_t h0, h1, l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+    hi = __builtin_bit_cast(f16x4, u2{h0, h1});
+    lo = __builtin_bit_cast(f16x4, u2{l0, l1});
+}
+
+// N x ds_read_b128 (N = 2 | 4, rows STEP bytes apart) issued back to back and waited for inside ONE statement, hidden from hipcc's
+// waitcnt bookkeeping.  Why: beside an LDS-DMA in flight (the GEMM's chained prefetch of the next tile) hipcc puts
+// `s_waitcnt vmcnt(0)` in front of every ordinary LDS read (the DMA might write what is read) -- a drain of the prefetch AND of the
+// previous interval's output stores -- and emits read / wait / store one after the other: 4 exposed LDS latencies + a memory
+// round trip per epilogue interval (profiles/r03_gemm_epilogue_ablation.txt).  The image read here was written by ds_write
+// before the workgroup barrier the caller has passed; the LDS-DMA never targets it while it is live.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// V = u32x4 | f32x4: take the element type the values are USED as (hipcc miscompiles __builtin_bit_cast(float, v[k][j]) on a u32x4
+// statement output -- every element becomes element 0, seen in the residual epilogue, ROCm 7.2)
+template <int STEP, typename V>
+__device__ __forceinline__ void lds_read_rows4(const void* p, V (&v)[4]) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%c5\n\tds_read_b128 %2, %4 offset:%c6\n\tds_read_b128 %3, %4 offset:%c7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(lds_addr(p)), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP) : "memory");
+}
+template <int STEP, typename V>
+__device__ __forceinline__ void lds_read_rows2(const void* p, V (&v)[2]) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%c3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(lds_addr(p)), "i"(STEP) : "memory");
+}
+
 #define VTQ_WAVE 64
 
 #ifdef __HIPCC__

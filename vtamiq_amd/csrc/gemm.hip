@@ -86,7 +86,8 @@ struct EpiDiag {};
 #define VTQ_EPI_T1(field)
 #endif
 
-template <typename T, int OPL, int EPI, int MH, bool SCALED>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
+// BIASED: the accumulators were initialised with the bias (gemm_pp2_kernel init_acc), so the forms below add nothing
+template <typename T, int OPL, int EPI, int MH, bool SCALED, bool BIASED>      // MH = 2: 256-row tile, MH = 1: 128-row half tile (rows m0 .. m0+127)
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2][4][2], char* smem, int tid, int wr, int wc,
                                             int fr, int fq, int64_t m0, int n0, EpiDiag& ed) {
     typedef typename Vec<T>::x4 tx4;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int n = n0 + nh * 128 + wc * 32 + ni * 16 + fq * 4;
-            b4[nh][ni] = *(const float4*)(p.bias + n);
+            if constexpr (!BIASED) b4[nh][ni] = *(const float4*)(p.bias + n);
             if constexpr (EPI == EPI_RESID) g4[nh][ni] = p.gamma ? *(const float4*)(p.gamma + n) : float4{1.f, 1.f, 1.f, 1.f};
         }
 
@@ -151,10 +152,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                         const f32x4 a = acc[mh][nh][2 * q + e][ni];
                         const float4 bb = b4[nh][ni];
                         float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
-                        if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
-                        }
+                        if constexpr (EPI == EPI_BIAS_GELU) gelu_erf4(v);
                         amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
                         *(uint32_t*)(img + lrow * RS + col) = pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
                     }
@@ -164,11 +162,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             const char* img = smem + STG + (pass & 1) * IMG;
             const int c16 = tid & 15, r0 = tid >> 4;    // 16 threads x 16 B per 256-byte row, 32 rows per sweep
             char* og = (char*)p.out + m0 * p.ldo + n0 + c16 * 16;
+            u32x4 v[2];
+            lds_read_rows2<32 * RS>(img + r0 * RS + c16 * 16, v);
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {            // image row ps*32 + r0 = (wr = ps, e = r0 >> 4, fr = r0 & 15)
                 const int grow = mh * 128 + ps * 64 + (2 * q + (r0 >> 4)) * 16 + (r0 & 15);
-                const uint4 v = *(const uint4*)(img + (ps * 32 + r0) * RS + c16 * 16);
-                store_nt16(og + (int64_t)grow * p.ldo, v);
+                store_nt16(og + (int64_t)grow * p.ldo, uint4{v[ps][0], v[ps][1], v[ps][2], v[ps][3]});
             }
         };
         convert(0);
@@ -203,14 +202,20 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                         tx4 h;
                         if (pl == 0) {
                             const f32x4 a = acc[mh][nh][2 * q + e][ni];
-                            const float4 bb = b4[nh][ni];
-                            float v[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
-                            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+                            float v[4] = {a[0], a[1], a[2], a[3]};
+                            if constexpr (!BIASED) {
+                                const float4 bb = b4[nh][ni];
+                                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                             }
+#if !(defined(VTQ_EPI_ABL) && VTQ_EPI_ABL == 1)                           // measurement build 1: no GELU arithmetic
+                            if constexpr (EPI == EPI_BIAS_GELU) gelu_erf4(v);
+#endif
                             if constexpr (NP == 1) {
                                 h = tx4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                            } else if constexpr (std::is_same<T, f16>::value) {
+                                tx4 l;
+                                split4_f16(v, h, l);
+                                lo[li] = l;
                             } else {
                                 tx4 l;
 #pragma unroll
@@ -220,7 +225,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                         } else {
                             h = lo[(NP == 1) ? 0 : li];
                         }
+#if defined(VTQ_EPI_ABL) && VTQ_EPI_ABL == 4                               // measurement build 4: no LDS staging either
+                        asm volatile("" ::"v"(h));
+                        (void)img; (void)lrow; (void)col;
+#else
                         *(tx4*)(img + lrow * RS + col * 2) = h;
+#endif
                     }
         };
         auto copy_out = [&](int pass) {
@@ -228,12 +238,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             const char* img = smem + STG + (pass & 1) * IMG;
             const int c16 = tid & 31, r0 = tid >> 5;
             T* og = (T*)p.out + pl * p.o_plane + m0 * p.ldo + n0 + c16 * 8;
+#if defined(VTQ_EPI_ABL) && (VTQ_EPI_ABL == 2 || VTQ_EPI_ABL == 4)          // measurement builds: no copy-out at all
+            (void)img; (void)og; (void)mh; (void)q; (void)r0; (void)c16;
+#else
+            u32x4 v[4];
+            lds_read_rows4<16 * RS>(img + r0 * RS + c16 * 16, v);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {            // image row ps*16 + r0 = (wr = ps>>1, e = ps&1, fr = r0)
                 const int grow = mh * 128 + (ps >> 1) * 64 + (2 * q + (ps & 1)) * 16 + r0;
-                const uint4 v = *(const uint4*)(img + (ps * 16 + r0) * RS + c16 * 16);
-                store_nt16(og + (int64_t)grow * p.ldo, v);
+#if defined(VTQ_EPI_ABL) && VTQ_EPI_ABL == 3                               // measurement build: LDS read kept, global store dropped
+                asm volatile("" ::"v"(v[ps])); (void)grow;
+#else
+                store_nt16(og + (int64_t)grow * p.ldo, uint4{v[ps][0], v[ps][1], v[ps][2], v[ps][3]});
+#endif
             }
+#endif
         };
         // Within an interval the two wave groups (the two waves of every SIMD) run the two steps in OPPOSITE order -- they touch
         // different images, so either order is valid -- so that one wave's VALU conversion runs while its SIMD partner sits in
@@ -276,8 +295,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                 for (int ni = 0; ni < 2; ++ni) {
                     const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
                     const f32x4 a = acc[mh][nh][mi][ni];
-                    const float4 bb = b4[nh][ni], gg = g4[nh][ni];
-                    const float4 v = {gg.x * (a[0] + bb.x), gg.y * (a[1] + bb.y), gg.z * (a[2] + bb.z), gg.w * (a[3] + bb.w)};
+                    const float4 gg = g4[nh][ni];
+                    float4 v;
+                    if constexpr (BIASED) v = float4{gg.x * a[0], gg.y * a[1], gg.z * a[2], gg.w * a[3]};
+                    else {
+                        const float4 bb = b4[nh][ni];
+                        v = float4{gg.x * (a[0] + bb.x), gg.y * (a[1] + bb.y), gg.z * (a[2] + bb.z), gg.w * (a[3] + bb.w)};
+                    }
                     *(float4*)(img + (wr * 16 + fr) * RS + col * 4) = v;
                 }
         };
@@ -289,11 +313,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         };
         auto copy_out = [&](int ch) {
             const char* img = smem + STG + (ch & 1) * IMG;
+            f32x4 dv[4];
+            lds_read_rows4<8 * RS>(img + r0 * RS + c16 * 16, dv);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {            // image row ps*8 + r0 = (wr = ps>>1, fr = (ps&1)*8 + r0)
-                const float4 d = *(const float4*)(img + (ps * 8 + r0) * RS + c16 * 16);
                 float4 x = xv[ch & 1][ps];
-                x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+                x.x += dv[ps][0]; x.y += dv[ps][1]; x.z += dv[ps][2]; x.w += dv[ps][3];
                 *(float4*)(xg + (int64_t)grow_of(ch, ps) * p.N) = x;
             }
         };
@@ -420,6 +445,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     const int64_t w_d2 = (TERMS == 1) ? (int64_t)64 * p.K * ES : ((TERMS == 3) ? p.w_plane * 2 : 0);
     f32x4 acc[2][2][4][2];
     tx8 fa[NFA], fb0[NFB], fb1[NFB];
+    // The accumulators start at the BIAS instead of at zero (16-bit forms with a staged epilogue): the bias vector lives in LDS for
+    // the whole persistent launch (kBiasLds .. + 4 N bytes, above the ring and the epilogue images) and every accumulator block
+    // is initialised by one ds_read_b128 of its four columns.  That removes two vector instructions per output from the
+    // vector-issue-bound epilogue -- the v_mov that zeroed the register and the bias add (profiles/r03_gemm_epilogue_stamps.txt).
+    constexpr bool kBiasInAcc = !F8 && EPI != EPI_EMBED;
+    constexpr int kBiasLds = 147456;
+    if constexpr (kBiasInAcc) {
+        for (int i = threadIdx.x * 4; i < p.N; i += 2048) *(float4*)(smem + kBiasLds + i * 4) = *(const float4*)(p.bias + i);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    auto init_acc = [&](int n0) {
+        int boff = kBiasLds + (n0 + wc * 32 + fq * 4) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        asm volatile("" : "+v"(boff));          // a load of its own for every block: a copy would be a vector instruction again
+                        acc[a][b][i][j] = *(const f32x4*)(smem + boff + (b * 128 + j * 16) * 4);
+                    }
+    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -568,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
         }
         tile_setup();
-        zero_acc();
+        if constexpr (!kBiasInAcc) zero_acc();
         if (kind == 0) {
             // ---- entry: groups 0, 1, 2 in flight, group 0 landed for everyone ------------------------------------------
             if (!chained) {
@@ -582,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
             __builtin_amdgcn_s_barrier();
             if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave group runs one barrier behind
+            if constexpr (kBiasInAcc) init_acc(n0);           // here, not at the top of the tile: the accumulators are dead until now
 
             VTQ_DIAG_LOOP_BEGIN()
             for (int kt = 0; kt < nkt; ++kt) {
@@ -623,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
             if (!(p.flags & GEMM_FLAG_NO_EPILOGUE))
-                pp_epilogue<TO, OPL, EPI, 2, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
+                pp_epilogue<TO, OPL, EPI, 2, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
@@ -661,6 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             if (wr == 1) __builtin_amdgcn_s_barrier();
+            if constexpr (kBiasInAcc) init_acc(n0);
             int slot = 0;                                      // kt % 3
             VTQ_DIAG_LOOP_BEGIN()
             for (int kt = 0; kt < nkt; ++kt) {
@@ -680,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
             VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();
-            pp_epilogue<TO, OPL, EPI, 1, F8>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
+            pp_epilogue<TO, OPL, EPI, 1, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             chained = false;
             if (it + 1 < it_end) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -868,7 +920,7 @@ int env_flags() {
 }
 
 template <typename T, int TERMS, int EPI> hipError_t launch_t(GemmArgs a, hipStream_t s) {
-    constexpr int LDS = 147456;                    // full tiles: DMA ring 128 KiB, epilogue images 256x528 B; half tiles: 3 x 48 KiB
+    constexpr int LDS = 163840;                    // full tiles: DMA ring 128 KiB, epilogue images 256x528 B; half tiles: 3 x 48 KiB; bias vector (N <= 4096) above 144 KiB
     static std::mutex mu;
     static bool configured[64] = {false};          // hipFuncSetAttribute is per device
     int dev = 0;
@@ -930,7 +982,7 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) {
     const int bk2 = (num.f16 == 2) ? 256 : ((num.terms == 1) ? 128 : 64);     // two K tiles: the DMA ring's buffer parity is fixed across tiles
-    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.K <= 0 || a.K % bk2 || a.lda % 16 || !num_valid(num)) return hipErrorInvalidValue;
+    if (a.M <= 0 || a.M % 256 || a.N % 256 || a.N > 4096 || a.K <= 0 || a.K % bk2 || a.lda % 16 || !num_valid(num)) return hipErrorInvalidValue;
     if (num.f16 == 2) {
         if (!a.wscale) return hipErrorInvalidValue;
         return launch_e<f8, 1>(a, epilogue, s);
