@@ -470,6 +470,45 @@ def test_operand_range_overflow_is_reported():
         strict(p, ps, sc)
 
 
+def test_default_model_has_no_silent_nans():
+    """The DEFAULT-constructed drop-in (precision='auto') on the same 1e7-gain weights: the fp32 reference
+    returns finite scores there (train.py:602-607), so must the drop-in, without the user calling anything: the fp16 operand
+    overflow is noticed after the forward, the model switches itself to bf16x3 (fp32 operand range) with a warning, repeats the
+    call and returns scores within the bf16x3 bound of the fp32 oracle.  A healthy model stays in fp16x3 and equals the explicit mode
+    bit for bit; a position outside [0, 1) raises the reference's IndexError."""
+    import warnings
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    auto = VTAMIQ(**json.loads(json.dumps(kw)))                 # no precision argument
+    assert auto.precision == "auto"
+    auto.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    auto = auto.to(DEV).eval()
+    with torch.no_grad():
+        q_auto = auto(p, ps, sc)[0]
+        q_x3 = build(kw, sd, "fp16x3")(p, ps, sc)[0]
+    assert auto.engine_precision == "fp16x3" and torch.equal(q_auto, q_x3)
+    bad_sd = {k: v.copy() for k, v in sd.items()}
+    bad_sd["transformer.encoder.layers.0.attention_norm.weight"][:4] *= 1e7
+    bad = VTAMIQ(**json.loads(json.dumps(kw)))
+    bad.load_state_dict({k: torch.from_numpy(v) for k, v in bad_sd.items()})
+    bad = bad.to(DEV).eval()
+    with warnings.catch_warnings(record=True) as w, torch.no_grad():
+        warnings.simplefilter("always")
+        q = bad(p, ps, sc)[0]
+    assert any("bf16x3" in str(x.message) for x in w)
+    assert bad.engine_precision == "bf16x3" and bool(torch.isfinite(q).all())
+    q_ref = O.vtamiq_forward(O.to_torch(bad_sd), spec, *split_inputs(patches, pos, scales))[0].numpy()
+    e = rel_err(q.cpu().numpy(), q_ref)
+    print(f"\n[auto -> bf16x3 on the 1e7-gain weights] {e}")
+    assert gate(q.cpu().numpy(), q_ref, TOL["bf16x3"]), e
+    with torch.no_grad():                                       # sticky: the next call runs bf16x3 directly, same scores
+        assert torch.equal(bad(p, ps, sc)[0], q)
+    oob = tuple(t.clone() for t in ps)
+    oob[0][0, 3, 1] = 1.0                                       # pos == 1.0: one past the table (transformer.py:417-421)
+    with pytest.raises(IndexError), torch.no_grad():
+        auto(p, oob, sc)
+
+
 @pytest.mark.parametrize("precision", ["fp16x3", "fp16", "fp8"])
 def test_repeated_forwards_are_bitwise_identical(precision):
     """Race detector for the persistent GEMM (DMA ring chained across tile boundaries, counted vmcnt, raw barriers) and every other

@@ -252,7 +252,11 @@ class VTAMIQ(nn.Module):
 
     # ---- engine management --------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        ps = self.__dict__.get("_param_cache")
+        if ps is None:                               # the parameter OBJECTS are fixed after construction (.to() / load_state_dict
+            ps = list(self.parameters())             # write into them): walk the module tree once, not on every forward
+            self.__dict__["_param_cache"] = ps
+        return tuple((p.data_ptr(), p._version) for p in ps)
 
     def _release_engine(self):
         eng = self.__dict__.get("_engine")
@@ -362,8 +366,9 @@ class VTAMIQ(nn.Module):
             self._weights_sig = sig
         return lib
 
-    def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameters are replaced
+    def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameter storage (possibly the objects) is replaced
         self._weights_sig = None
+        self.__dict__["_param_cache"] = None
         return super()._apply(fn, *a, **k)
 
     # ---- the hot path ---------------------------------------------------------------------------------------
