@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Builds the round-3 evidence files under profiles/ from the raw collection merged back into gpurun_out/r03p by
+tools/collect_profiles_r03.sh.  (The one-off measurements of the round -- in-kernel clock, shadow VALU, epilogue stamps and
+ablations, A/B against the round-2 tree, traffic of the four GEMMs, mode fidelity, head eager vs hipGraph -- were written to
+profiles/ directly from their tools/runs/ scripts' outputs.)   Run in the repo after the gpurun call:  python tools/make_profiles_r03.py"""
+import collections, csv, glob, io, json, os, sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out", "r03p")
+P = os.path.join(ROOT, "profiles")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import summarize_prof as SP  # noqa: E402
+
+
+def cap(fn, *a):
+    b = io.StringIO()
+    with redirect_stdout(b):
+        fn(*a)
+    return b.getvalue()
+
+
+def clean(name, keep=None):
+    out = []
+    for ln in open(os.path.join(G, name), errors="replace"):
+        if "amdgpu.ids" in ln or "UserWarning" in ln or "warnings.warn" in ln:
+            continue
+        if keep is None or keep(ln):
+            out.append(ln.rstrip("\n"))
+    return "\n".join(out) + "\n"
+
+
+def write(name, text):
+    open(os.path.join(P, name), "w").write(text)
+    print("wrote profiles/" + name, len(text), "bytes")
+
+
+def pmc_table(d, pat):
+    f = glob.glob(os.path.join(G, d) + "/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            k = SP.short(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+    return {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
+
+
+line = [l for l in open(os.path.join(G, "bench_line.json")) if l.startswith('{"metric"')][-1]
+write("r03_bench_line.json", line)
+lh = [l for l in open(os.path.join(G, "bench_line_headline_profiled.json")) if l.startswith('{"metric"')][-1]
+dh = json.loads(lh)
+write("r03_bench_line_headline_profiled.json", lh)
+write("r03_bench_headline_kernel_stats.txt",
+      "# command: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-second-mode --no-north-star --no-fidelity --no-sustained --no-live-traffic\n"
+      "# (only the headline mode at B = 32 runs: 5 warm-up + 20 timed forwards)\n"
+      f"# the same process printed roofline.avg_launch_ms = {dh['roofline']['avg_launch_ms']:.4f} ms for gemm_pp2_kernel<f16, 3, 1> (fc1, HIP events on the\n"
+      "# launch stream inside the timed region); the rocprofv3 average below covers warm-up + timed launches of the same kernel.\n"
+      + cap(SP.stats, os.path.join(G, "stats")))
+
+t1, t2 = pmc_table("gemm_pmc", "gemm"), pmc_table("gemm_pmc2", "gemm")
+txt = ["# command: rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/gemm_bench.py --only fc1 --rounds 1 --fmt fp16x3 fp16x2 fp16 bf16x3 fp8",
+       "# fc1 GEMM of BASELINE configs[1]: M = 32256 (64 sequences x 501 rows, padded), N = 3072, K = 768, GELU epilogue; mean per dispatch.",
+       "# GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* are summed over the 256 CUs (x4 SIMDs for the per-SIMD busy counters).",
+       "# Round-3 kernel: bias in the accumulators (LDS bias image), hand-ordered 4-wide GELU, 6-instruction hi/lo split, copy-out LDS reads hidden from hipcc.", ""]
+txt.append(cap(SP.pmc, os.path.join(G, "gemm_pmc"), "gemm"))
+txt.append(cap(SP.pmc, os.path.join(G, "gemm_pmc2"), "gemm"))
+txt.append("# derived (per kernel): cycles per XCD = GRBM_GUI_ACTIVE / 8; MFMA-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles per XCD)")
+for k, v in t1.items():
+    cyc = v["GRBM_GUI_ACTIVE"] / 8
+    busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
+    extra = t2.get(k, {})
+    txt.append(f"#   {k:34s} cycles/XCD {cyc:9.0f}   MFMA busy {busy*100:5.1f} %   MFMA insts {v['SQ_INSTS_MFMA']:.3e}   LDS bank-conflict cycles/CU "
+               f"{v['SQ_LDS_BANK_CONFLICT']/256:8.0f}   VALU insts (incl. MFMA) {extra.get('SQ_INSTS_VALU', 0):.3e}")
+txt += ["", "# Round 2 (profiles/r02_gemm_fc1_pmc.txt): fp16x3 666806 cycles/XCD, MFMA busy 65.3 %, 5.900e+07 VALU insts; fp16 319248 cycles, 45.5 %, 3.399e+07.",
+        "# In-kernel view of the same kernel (s_memtime stamps, diagnostic build): profiles/r03_clock.txt (clock), r03_gemm_epilogue_stamps.txt,",
+        "# r03_gemm_epilogue_ablation.txt (where the epilogue's cycles go), r03_gemm_ab_vs_r02.txt (same-box wall-time A/B against the round-2 tree).",
+        "", "# unprofiled, epilogue skipped (VTQ_GEMM_FLAGS=8, values wrong by design) against the full kernels:", clean("gemm_bench_noepi.txt")]
+write("r03_gemm_fc1_pmc.txt", "\n".join(txt))
+
+f = pmc_table("fetch", "gemm"); w = pmc_table("write", "gemm")
+names = {"fp16x3": "gemm_pp2_kernel<f16, 3, 1>", "fp16x2": "gemm_pp2_kernel<f16, 2, 1>", "fp16": "gemm_pp2_kernel<f16, 1, 1>", "fp8": "gemm_pp2_kernel<f8, 1, 1>"}
+bfk = [k for k in f if "garbled" in k or k.startswith("gemm_pp2_kernel<bf16")]
+if bfk:
+    names["bf16x3"] = bfk[0]
+M, N, K = 32256, 3072, 768
+alg = {"fp16x3": (M * K * 4 + N * K * 4, M * N * 4), "bf16x3": (M * K * 4 + N * K * 4, M * N * 4), "fp16x2": (M * K * 4 + N * K * 2, M * N * 4),
+       "fp16": (M * K * 2 + N * K * 2, M * N * 2), "fp8": (M * K + N * K, M * N)}
+js = {"kernel": "gemm_pp2_kernel<T, TERMS, GELU> (fc1), M=32256 N=3072 K=768 (B=32 pairs)",
+      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/gemm_bench.py --only fc1; see r03_gemm_fc1_traffic.txt",
+      "note": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; L2-miss side bytes, "
+              "Infinity-Cache hits included"}
+tt = ["# commands: rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/gemm_bench.py --only fc1 --rounds 1 --fmt fp16x3 fp16x2 fp16 bf16x3 fp8",
+      "#           rocprofv3 --pmc WRITE_SIZE --kernel-trace -- (same)          separate passes; units KiB; mean per dispatch", "",
+      cap(SP.pmc, os.path.join(G, "fetch"), "gemm"), cap(SP.pmc, os.path.join(G, "write"), "gemm"),
+      "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B requests at 64 B -> x2; WRITE_SIZE exact.  Both are the L2's",
+      "# memory-side request counters: reads served by the 256 MiB Infinity Cache are INCLUDED (they are L2 misses, not HBM reads)."]
+for mode, kn in names.items():
+    if kn not in f:
+        continue
+    rd, wr = 2 * f[kn]["FETCH_SIZE"] * 1024, w[kn]["WRITE_SIZE"] * 1024
+    a_r, a_w = alg[mode]
+    js[mode] = {"FETCH_SIZE_KiB": f[kn]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[kn]["WRITE_SIZE"], "bytes_per_launch": rd + wr,
+                "algorithmic_bytes_per_launch": a_r + a_w}
+    tt.append(f"# {mode:7s}: read 2 x {f[kn]['FETCH_SIZE']:.0f} KiB = {rd/1e6:6.1f} MB (algorithmic A + W {a_r/1e6:6.1f} MB), write {wr/1e6:6.1f} MB "
+              f"(algorithmic {a_w/1e6:6.1f} MB) -> {(rd+wr)/1e6:6.1f} MB per launch")
+tt += ["#", "# All four encoder GEMMs with their L2 hit rates: profiles/r03_gemm_traffic.txt."]
+write("r03_gemm_fc1_traffic.txt", "\n".join(tt))
+write("r03_gemm_fc1_traffic.json", json.dumps(js, indent=1))
+
+ta = pmc_table("attn_pmc", "attention")
+at = ["# command: rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES",
+      "#          SQ_WAIT_INST_ANY --kernel-trace -- python3 tools/attn_bench.py --fmt fp16x3 fp16   (64 sequences x 501 tokens x 12 heads x 64: the encoder shape at B=32)",
+      "# The attention kernel is the round-2 kernel (the round's experiments on it -- cheaper P split, start stagger, two query blocks per wave -- did not pay:",
+      "# profiles/r03_valu_diet_ab.txt, r03_attention_qb2.txt).", "",
+      cap(SP.pmc, os.path.join(G, "attn_pmc"), "attention"), "# derived: cycles/XCD = GRBM_GUI_ACTIVE / 8; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x cycles)"]
+for k, v in ta.items():
+    cyc = v["GRBM_GUI_ACTIVE"] / 8
+    at.append(f"#   {k:52s} cycles/XCD {cyc:9.0f}  MFMA busy {v['SQ_VALU_MFMA_BUSY_CYCLES']/1024/cyc*100:5.1f} %  VALU insts (incl. MFMA) per MFMA inst "
+              f"{v['SQ_INSTS_VALU']/v['SQ_INSTS_MFMA']:5.1f}  LDS bank conflicts {v['SQ_LDS_BANK_CONFLICT']:.0f}")
+at += ["", "# unprofiled (python3 tools/attn_bench.py --fmt fp16x3 fp16 bf16x3):", clean("attn_bench.txt")]
+write("r03_attention_pmc.txt", "\n".join(at))
+
+write("r03_gemm_bench.txt", "# python3 tools/gemm_bench.py --fmt fp16x3 fp16x2 fp16 bf16x3 bf16 fp8   (encoder GEMM shapes at B=32; median of 7 rounds x 5 launches)\n"
+      + clean("gemm_bench.txt"))
+write("r03_class_profile.txt", "# python3 tools/class_profile.py   (HIP events on the launch stream around every kernel class; BASELINE configs[1], B=32, N=500)\n"
+      + clean("class_profile.txt"))
+write("r03_configs.txt", "# python3 tools/run_config.py ...: the other BASELINE / reference shapes end to end on one MI355X (timing + one pair against the oracle)\n"
+      "# configs[3]: --variant ViT-L16 --batch 16 --patches 1024 --scales 3\n" + clean("config3_vitl.txt")
+      + "# reference default topology (train_config.py:169-194): --variant ViT-B16 --batch 16 --patches 512 --scales 5 --refdefault\n" + clean("refdefault.txt")
+      + "# long sequence: --variant ViT-B16 --batch 4 --patches 2500 --scales 1\n" + clean("n2500.txt"))
+write("r03_fp8_stage_parity.txt", "# python3 -m pytest tests/test_gpu_fp8.py -q -s   (GPU box): the fp8 mode with CALIBRATED activation scales against its fake-quant oracle fed the\n"
+      "# engine's own scales: teacher-forced stage parity, calibration against the oracle's, saturation on trained-like weights, end-to-end noise level\n"
+      + clean("fp8_tests.txt", keep=lambda l: l.startswith("[") or l.startswith("   ") or l.startswith(" oracle") or "stressed" in l or "passed" in l or "failed" in l))
+write("r03_fuzz_parity.txt", "# python3 tools/fuzz_parity.py --cases 150 --precision fp16x3   (GPU box): random topologies / shapes / inputs in the parity mode against the oracle\n"
+      + clean("fuzz.txt"))
