@@ -148,6 +148,11 @@ int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t
  * tiles; XCC id; then per wave the cycles spent in the epilogue conversion, copy-out and waits}; shadow = dummy VALU instructions (x8) issued in every LDS-read phase of the main loop (what vector work beside
  * the partner wave's MFMAs costs).  Returns 1 in a diagnostic build. */
 int  vtq_debug_gemm_diag(void* buf, int32_t shadow);
+/* Which of the two fused-attention kernels vtq_k_attention and the engine launch (process-wide; tests and measurement):
+ * 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel, -1 = the library's rule (the pipelined kernel for the 3-term
+ * formats when its 256-row blocks fill the chip; environment VTQ_ATTN_VARIANT overrides the rule).  Both compute the same arithmetic
+ * in the same order per query row: outputs are bit-identical. */
+int  vtq_debug_attention_variant(int32_t variant);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
 #define VTQ_K_CONVERT  0

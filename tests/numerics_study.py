@@ -35,7 +35,7 @@ from oracle import vtamiq_oracle as O          # noqa: E402
 from tests import helpers                     # noqa: E402
 
 SITES = ["patch", "qkv", "qk", "pv", "out", "fc1", "fc2"]
-MFMAS = {"x": 0, "b1": 1, "h1": 1, "b2a": 2, "b2w": 2, "h2a": 2, "h2w": 2, "b3": 3, "h3": 3}
+MFMAS = {"m2": 2, "m2t": 2, "m15": 1.5, "m15t": 1.5, "m25": 2.5, "m25t": 2.5, "x": 0, "b1": 1, "h1": 1, "b2a": 2, "b2w": 2, "h2a": 2, "h2w": 2, "b3": 3, "h3": 3}
 
 
 def _split(v, dt):
@@ -44,10 +44,49 @@ def _split(v, dt):
     return hi, lo
 
 
+def _mx8(v, kdim, block=32, tensor_scale=False):
+    """e4m3 rounding of v with one power-of-two scale per `block` elements along the contraction axis `kdim` (what the MX-scaled
+    MFMA's E8M0 operands provide), or one per tensor: the largest 2^k with max|v| * 2^k <= 448."""
+    v = v.movedim(kdim, -1)
+    K = v.shape[-1]
+    if tensor_scale:
+        amax = v.abs().max().clamp_min(1e-30).expand(1)
+        sc = torch.exp2(torch.floor(torch.log2(448.0 / amax)))
+        r = (v * sc).to(torch.float8_e4m3fn).float() / sc
+    else:
+        pad = (-K) % block
+        vp = F.pad(v, (0, pad)).reshape(*v.shape[:-1], -1, block)
+        amax = vp.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        sc = torch.exp2(torch.floor(torch.log2(448.0 / amax)))
+        r = ((vp * sc).to(torch.float8_e4m3fn).float() / sc).reshape(*v.shape[:-1], -1)[..., :K]
+    return r.movedim(-1, kdim)
+
+
 def emm(a, w_t, fmt):
     """a @ w_t with operands rounded per `fmt` (w_t already oriented [K, N] or batched)."""
     if fmt == "x":
         return a @ w_t
+    if fmt[0] == "m":
+        # fp16 hi*hi on the f16 MFMA + cross terms on the double-rate MX-scaled e4m3 MFMA:
+        #   m2  : + e4m3(a_hi) e4m3(w_lo) + e4m3(a_lo) e4m3(w_hi)        1 + 0.5 + 0.5 = 2 MFMA-equivalents / product
+        #   m15 : + e4m3(a_lo) e4m3(w_hi)  (weight lo dropped)            1.5
+        #   m25 : + a_lo w_hi in fp16 + e4m3(a_hi) e4m3(w_lo)             2.5
+        # suffix t: per-tensor instead of per-32-block scales
+        ts = fmt.endswith("t")
+        kind = fmt[1:].rstrip("t")
+        ah, al = _split(a, torch.float16)
+        wh, wl = _split(w_t, torch.float16)
+        q = lambda v, kd: _mx8(v, kd, tensor_scale=ts)
+        y = ah @ wh
+        if kind == "2":
+            y = y + q(a, -1) @ q(wl, -2) + q(al, -1) @ q(w_t, -2)
+        elif kind == "15":
+            y = y + q(al, -1) @ q(w_t, -2)
+        elif kind == "25":
+            y = y + al @ wh + q(a, -1) @ q(wl, -2)
+        else:
+            raise ValueError(fmt)
+        return y
     dt = torch.bfloat16 if fmt[0] == "b" else torch.float16
     kind = fmt[1:]
     ah, al = _split(a, dt)
@@ -170,6 +209,14 @@ SCHEMES = [
     ("h3, patch h1 + pv h2w + qk h2a", scheme("h3", patch="h1", pv="h2w", qk="h2a")),
     ("h3, out + fc2 h2a (weights single fp16 in the two residual-writing linears)", scheme("h3", out="h2a", fc2="h2a")),
     ("h3, out + fc2 + patch h2a", scheme("h3", out="h2a", fc2="h2a", patch="h2a")),
+    # cross terms on the double-rate e4m3 MFMA (linears only; attention keeps the 3-term fp16 form)
+    ("mx: linears m2 (hh + 2 e4m3 cross terms)", scheme("h3", patch="m2", qkv="m2", out="m2", fc1="m2", fc2="m2")),
+    ("mx: linears m2t (per-tensor scales)", scheme("h3", patch="m2t", qkv="m2t", out="m2t", fc1="m2t", fc2="m2t")),
+    ("mx: linears m25 (a_lo fp16, w_lo e4m3)", scheme("h3", patch="m25", qkv="m25", out="m25", fc1="m25", fc2="m25")),
+    ("mx: linears m15 (a_lo e4m3, w_lo dropped)", scheme("h3", patch="m15", qkv="m15", out="m15", fc1="m15", fc2="m15")),
+    ("mx: fc1 + fc2 m2, rest h3", scheme("h3", fc1="m2", fc2="m2")),
+    ("mx: qkv + fc1 m2, rest h3", scheme("h3", qkv="m2", fc1="m2")),
+    ("mx: everything m2 (attention too)", scheme("m2")),
 ]
 
 

@@ -376,6 +376,27 @@ def test_fp8_batch_invariance_and_order():
     assert np.array_equal(q1, q[1:2])
 
 
+def test_fp8_attention_kernels_agree():
+    """The e4m3 context bytes (and the activation-range report behind the calibration) of the pipelined attention kernel equal the
+    4-wave kernel's: same scores bit for bit with either forced (the library's own rule keeps single-plane attention on the 4-wave one)."""
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c2shape_b4_n500")
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    got = []
+    for variant in (0, 1):
+        lib.vtq_debug_attention_variant(variant)
+        try:
+            model = build(kw, sd)                       # calibrates on its first forward, through the forced kernel
+            with torch.no_grad():
+                got.append((model(p, ps, sc)[0].cpu().numpy(), model.fp8_scales()))
+                model.check_inputs()                    # no clamped activation with either kernel
+        finally:
+            lib.vtq_debug_attention_variant(-1)
+    assert np.array_equal(got[0][0], got[1][0])
+    assert got[0][1] == got[1][1]
+
+
 def test_fp8_pairwise_triplets_match_two_calls():
     """SURVEY 8f-2 in the fp8 mode: the fused (ref, dist1, dist2) entry point reproduces the two model calls bit for bit."""
     from vtamiq_amd import synth

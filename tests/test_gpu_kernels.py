@@ -143,15 +143,25 @@ def _attention_ref(qkv, nseq, S, S_pad, H):
 @pytest.mark.parametrize("nseq,S,H", [(4, 501, 768), (3, 51, 768), (2, 1025, 1024), (2, 64, 768), (2, 509, 768), (5, 521, 768), (3, 9, 768),
                                       (2, 96, 768)])
 @pytest.mark.parametrize("packed", [True, False])
-def test_attention(fmt, nseq, S, H, packed):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention(fmt, nseq, S, H, packed, variant):
+    """variant 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel (forced; the library's own rule picks per shape)."""
     lib = _lib.load()
+    lib.vtq_debug_attention_variant(variant)
+    try:
+        _attention_case(lib, fmt, nseq, S, H, packed)
+    finally:
+        lib.vtq_debug_attention_variant(-1)
+
+
+def _attention_case(lib, fmt, nseq, S, H, packed, spike_row=None):
     # sequence pitch: the engine packs sequences back to back (pitch = S: the last key tile / query block of a sequence runs
     # into the next one and is masked / not stored); a padded pitch must work as well
     S_pad = S if packed else (S + 31) // 32 * 32
     rows = nseq * S_pad + 128
     qkv = _randn(rows, 3 * H, seed=16, scale=1.5)
     # a spike so that the running max moves late in the sequence (online-softmax rescale path)
-    qkv[S - 3, H:H + 64] *= 6.0
+    qkv[S - 3 if spike_row is None else spike_row, H:H + 64] *= 6.0
     P = to_planes(qkv, fmt, "a")
     npl = P.shape[0]
     out = torch.zeros((npl, rows, H), dtype=elt_dtype(fmt), device=DEV)
@@ -162,6 +172,25 @@ def test_attention(fmt, nseq, S, H, packed):
     tol = {"bf16": 1.5e-2, "fp16": 3e-3, "bf16x3": 2e-4, "fp16x3": 1e-5}[fmt]
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
+    return out
+
+
+@pytest.mark.parametrize("fmt", ["fp16x3", "fp16", "bf16x3"])
+@pytest.mark.parametrize("nseq,S,H", [(24, 501, 768), (6, 1025, 1024), (3, 257, 768), (2, 2501, 768), (7, 64, 768)])
+def test_attention_kernels_agree_bitwise(fmt, nseq, S, H):
+    """The two kernels run the same arithmetic in the same order per query row: identical bits, also with the row maximum moving late and
+    sitting in either half-wave (keys whose score lands in lanes 32..63 exposed a dropped v_permlane32_swap in round 3), on ragged last
+    blocks (257, 1025: one valid row in the last 256-row block) and across the block seams of a persistent workgroup (24 x 12 x 2 blocks)."""
+    lib = _lib.load()
+    outs = []
+    for spike in (S - 3, S - 7 if S > 7 else 0):
+        for variant in (0, 1):
+            lib.vtq_debug_attention_variant(variant)
+            try:
+                outs.append(_attention_case(lib, fmt, nseq, S, H, True, spike_row=spike).view(torch.int16).clone())
+            finally:
+                lib.vtq_debug_attention_variant(-1)
+        assert torch.equal(outs[-2][:, : nseq * S], outs[-1][:, : nseq * S])
 
 
 def _skinny(x, W, bias, fmt, epi=0, post=None, gamma=None, res=None, aux=None, nsplit=0, want_y=True, ycols=None, planes_out=False,

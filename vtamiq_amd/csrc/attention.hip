@@ -25,6 +25,15 @@
 namespace vtq {
 namespace {
 
+// Diagnostic builds (-DVTQ_ATTN_DIAG, tools/build_abl.sh) accumulate per-wave s_memtime spans of the phases of a tile into the
+// buffer of gemm_set_diag (16 words per wave; tools/attn_probe.py); the shipped library executes no stamp.
+#ifdef VTQ_ATTN_DIAG
+#define VTQ_AT_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define VTQ_AT_SPAN(acc) { unsigned long long dg_t1; VTQ_AT_STAMP(dg_t1); acc += dg_t1 - dg_t; dg_t = dg_t1; }
+#else
+#define VTQ_AT_SPAN(acc)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
@@ -60,9 +69,29 @@ __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x
     }
 }
 
+// 3-term formats: the softmax scale (1/sqrt(64) * log2 e) is folded into Q once per query block -- q c = (hi + lo) c in fp32, split
+// again -- so that scores arrive in log2 units and the exponent is exp2(s - m): one subtraction that is EXACT for the row maximum at
+// any magnitude.  (The one-FMA form exp2(s c - m c) subtracts the rounded product m c: fine at ordinary logits, inf at the 1e13
+// logits of a 1e7-gain model, where the fp32 reference is finite; the single-plane formats keep it behind a magnitude guard, since
+// re-rounding q c to 11 bits would cost them accuracy.)
+template <typename T>
+__device__ __forceinline__ void prescale_q(typename Vec<T>::x8 (&qf)[2][4], float sc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = ((float)qf[0][t][j] + (float)qf[1][t][j]) * sc;
+            T a, b;
+            split2<T>(v, a, b);
+            qf[0][t][j] = a;
+            qf[1][t][j] = b;
+        }
+}
+
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out,
-                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale, Fp8Obs obs) {
+                                                        int64_t o_plane, int S, int S_pad, int H, float out8_scale, Fp8Obs obs,
+                                                        unsigned long long* diag, int q_log2) {
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
@@ -75,6 +104,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
+#ifdef VTQ_ATTN_DIAG
+    unsigned long long dg_k0, dg_r0, dg_t, dg_qk = 0, dg_sm = 0, dg_pv = 0, dg_bar = 0, dg_stage = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_k0), "=s"(dg_r0) :: "memory");
+#endif
     // 1-D grid, XCD-aware: the q-blocks of one (sequence, head) re-read the same K/V, so they must share an L2.
     // Blocks are dealt round-robin over the 8 XCDs; remap so each XCD owns a contiguous range of work ids (bijective).
     const int nqb = (S_pad + 127) / 128, nh = H / 64;
@@ -91,12 +124,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const int q_row = qb * 128 + wave * 32 + c;
 
     // ---- Q fragments: B operand of S^T = K Q^T, element j <-> d = 16t + 8hh + j ------------------------------
-    tx8 qf[NPL][4];
+    tx8 qf[2][4];
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             qf[pl][t] = *(const tx8*)(qkv + pl * plane + (row0 + q_row) * ld + head * 64 + 16 * t + 8 * hh);
+    if constexpr (NSPLIT == 3) { if (!q_log2) prescale_q<T>(qf, 0.125f * 1.4426950408889634f); }
 
     // ---- DMA source offsets (elements) of this thread for the two rounds of a 64-row tile --------------------
     uint32_t k_off[KB], v_off[KB];
@@ -141,9 +175,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
+#ifdef VTQ_ATTN_DIAG
+    unsigned long long dg_loop0, dg_loop1;
+    VTQ_AT_STAMP(dg_loop0);
+#endif
     for (int t = 0; t < nt; ++t) {
         const int nxt = cur ^ 1;
+#ifdef VTQ_ATTN_DIAG
+        VTQ_AT_STAMP(dg_t);
+#endif
         if (t + 1 < nt) stage(t + 1, nxt);
+        VTQ_AT_SPAN(dg_stage);
         const char* sk = smem + cur * STAGE;
         const char* sv = sk + NPL * TB;
 
@@ -165,6 +207,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             }
         }
 
+        VTQ_AT_SPAN(dg_qk);
         // ---- online softmax (base-2 domain; scale folded into one FMA per score) -----------------------------------
         if ((t + 1) * KT > S) {                 // wave-uniform: only the last tile(s) hold padded keys
 #pragma unroll
@@ -181,19 +224,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);                                              // raw (unscaled) running max
+        const float m_new = fmaxf(m_run, mx);                                              // running max (3-term: log2 units; else raw)
         const float nm = -m_new * sc;
         float rs = 0.f;
+        if constexpr (NSPLIT == 3) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
-                sacc[kb][r] = pv;
-                rs += pv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+                    sacc[kb][r] = pv;
+                    rs += pv;
+                }
+        } else
+        // single plane: exp2(s c - m c) as ONE FMA per score is exact enough only while |m c| is small: the FMA subtracts the ROUNDED
+        // product m c, so the maximum's own exponent is the rounding error of m c (2^-24 |m c|) instead of 0 -- harmless at |m c| <= 64
+        // (3e-6), inf at the logits of a 1e7-gain model (the fp32 reference returns finite scores there).  Beyond 64: subtract first.
+        if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f((sacc[kb][r] - m_new) * sc);
+                    sacc[kb][r] = pv;
+                    rs += pv;
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
+                    sacc[kb][r] = pv;
+                    rs += pv;
+                }
+        }
         if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {        // some row's max moved: rescale (exact; usually skipped)
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            const float alpha = __builtin_amdgcn_exp2f(NSPLIT == 3 ? m_run - m_new : (m_run - m_new) * sc);
             l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -202,6 +269,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         }
         m_run = m_new;
         l_run += rs;
+        VTQ_AT_SPAN(dg_sm);
 
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q] -------------------------------------------------------------
 #pragma unroll
@@ -237,11 +305,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                 }
             }
 
+        VTQ_AT_SPAN(dg_pv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 has landed
         __syncthreads();
+        VTQ_AT_SPAN(dg_bar);
         cur = nxt;
     }
 
+#ifdef VTQ_ATTN_DIAG
+    VTQ_AT_STAMP(dg_loop1);
+#endif
     // ---- normalise and write merged heads: out[row][head*64 + d] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -261,6 +334,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                     *(uint32_t*)((uint8_t*)out + (row0 + q_row) * H + head * 64 + dcol) =
                         pack_fp8x4(v[0] * out8_scale, v[1] * out8_scale, v[2] * out8_scale, v[3] * out8_scale);
                 } else if constexpr (NSPLIT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));        // rounded product, then converted (no fused form)
                     tx4 hv = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                     *(tx4*)(o + dcol) = hv;
                 } else {
@@ -273,14 +348,610 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             }
     }
     if (out8_scale > 0.f) fp8_report(obs, amax8, out8_scale);
+#ifdef VTQ_ATTN_DIAG
+    if (diag) {
+        unsigned long long dg_k1, dg_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_k1), "=s"(dg_r1) :: "memory");
+        if (lane == 0) {          // one 16-word slot per wave, plain stores (same-address atomics of 12 k waves would take a millisecond)
+            unsigned long long* dq = diag + ((size_t)blockIdx.x * 4 + wave) * 16;
+            dq[0] = dg_k1 - dg_k0; dq[1] = dg_r1 - dg_r0; dq[2] = dg_qk; dq[3] = dg_sm; dq[4] = dg_pv; dq[5] = dg_bar; dq[6] = 1; dq[7] = nt; dq[8] = dg_stage;
+            dq[9] = dg_loop0 - dg_k0; dq[10] = dg_k1 - dg_loop1;
+        }
+    }
+#endif
+}
+
+
+// =====================================================================================================================
+// Helpers of the software-pipelined kernel below.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// LDS fragment reads hidden from hipcc's waitcnt bookkeeping ("=v" outputs; the consumer is fenced by an s_waitcnt statement that names
+// the destinations "+v": cdna_hip_programming.md 'What hipcc does not do', form (ii))
+#define PP_DS_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(addr), "i"(off))
+#define PP_DS_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(addr), "i"(off))
+
+template <typename T, int NSPLIT>
+struct PPFrags {                      // three rolling fragment buffers: group g uses slot g % 3
+    u32x4 ka[3], kl[3];               // QK^T groups: K fragment hi / lo (ds_read_b128)
+    u32x2 va0[3], va1[3], vl0[3], vl1[3];   // PV groups: V^T fragment halves hi / lo (ds_read_b64_tr_b16)
+};
+
+// =====================================================================================================================
+// Software-pipelined form (used for the 3-term formats when 256-row blocks fill the chip; launch_attention).
+// Workgroup = 8 waves = 256 query rows, PERSISTENT over a contiguous list of (sequence, head, 256-row block) items -- the blocks of one
+// (sequence, head) are consecutive, so their K/V come from L2 the second time -- with ONE continuous stream of 64-key K/V tiles through
+// a 4-deep LDS ring (slot = stream index & 3) that does not stop at block seams.  Every wave runs one instruction stream per tile in
+// which the vector work sits in the shadow of its own MFMAs (cdna_hip_programming.md 'one-wave-per-SIMD' rules: <= 5 issues and
+// <= 1 transcendental per MFMA gap; sched_group_barrier):
+//   phase 1: the 24 MFMAs of QK^T of tile t + 1  ||  hi / lo split of P(t), rescale of O when the running max moved
+//   phase 2: the 24 MFMAs of PV of tile t          ||  softmax of tile t + 1 (max, exp2, row sum)
+// LDS fragments are read two groups (6 MFMAs) ahead by asm reads with counted lgkmcnt; one s_barrier per tile.  In iteration t every
+// wave issues its eighth of tile t + 3 (ring slot last read in iteration t - 1); at the end of the iteration vmcnt(NI) -- everything
+// but that tile has landed -- precedes the barrier.  At a block seam: the next block's Q is loaded IN PLACE (asm, hidden from hipcc's
+// vmcnt bookkeeping, which would otherwise drain the LDS-DMA in every iteration) right after the last QK^T that needs the old Q and
+// completes behind the same counted wait; the finished block's O is normalised, split and staged through 4 KB of LDS per wave in the
+// middle of the NEXT iteration (phase 1 does not touch O), so that its stores are 16 B per lane on whole 128-byte row segments, older
+// than that iteration's LDS-DMA and covered by its phase 2.  Waves whose rows lie behind the sequence (ragged last block) only load.
+// Same arithmetic in the same order per query row as attention_kernel: outputs are bit-identical (tools/attn_ab.py, tests).
+// Measurements, the skeleton ablations behind the switches below and the ping-pong variant that lost: profiles/r03_attention_anatomy.txt.
+#ifndef VTQ_SW_NOFILL
+#define VTQ_SW_NOFILL 0
+#endif
+#ifndef VTQ_SW_NOSTORE
+#define VTQ_SW_NOSTORE 0
+#endif
+#ifndef VTQ_SW_NOQ
+#define VTQ_SW_NOQ 0
+#endif
+#ifndef VTQ_SW_NODMA
+#define VTQ_SW_NODMA 0
+#endif
+#ifndef VTQ_SW_NOMFMA
+#define VTQ_SW_NOMFMA 0
+#endif
+template <typename T>
+__device__ __forceinline__ f32x16 SW_MFMA(typename Vec<T>::x8 a, typename Vec<T>::x8 b, f32x16 c) {
+#if VTQ_SW_NOMFMA
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#else
+    return mfma32<T>(a, b, c);
+#endif
+}
+#define SW_MFMA_VALU(n)                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+    __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+
+template <typename T>
+__device__ __forceinline__ void split_p4(const float (&p)[4], uint32_t (&hw)[2], uint32_t (&lw)[2]) {
+    if constexpr (std::is_same<T, f16>::value) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * j], p[2 * j + 1]);
+            const h2 hh = __builtin_bit_cast(h2, hp);
+            hw[j] = __builtin_bit_cast(uint32_t, hp);
+            lw[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p[2 * j] - (float)hh[0], p[2 * j + 1] - (float)hh[1]));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t h[2], l[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t hb = __builtin_bit_cast(uint32_t, p[2 * j + e]) & 0xFFFF0000u;
+                const float hf = __builtin_bit_cast(float, hb);
+                h[e] = hb >> 16;
+                l[e] = (uint32_t)__builtin_bit_cast(unsigned short, (bf16)(p[2 * j + e] - hf));
+            }
+            hw[j] = h[0] | (h[1] << 16);
+            lw[j] = l[0] | (l[1] << 16);
+        }
+    }
+}
+
+template <typename T, int NSPLIT>
+__global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out, int64_t o_plane,
+                                                           int S, int S_pad, int H, int nblk, int per, float out8_scale, Fp8Obs obs,
+                                                           unsigned long long* diag, int q_log2) {
+    typedef typename Vec<T>::x8 tx8;
+    typedef typename Vec<T>::x4 tx4;
+    constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
+    constexpr int KT = 64, TB = KT * 128, STAGE = TB * NPL * 2, NI = 2 * NPL;
+    constexpr int RPV = NSPLIT == 1 ? 2 : 4, RQK = NSPLIT == 1 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int nqb = (S_pad + 255) / 256, nh = H / 64;
+    const int nt = (S + KT - 1) / KT;
+    const int ld = 3 * H;
+    const int b0 = blockIdx.x * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    if (b0 >= b1) return;
+    const int NT = (b1 - b0) * nt;
+    const float sc = 0.125f * 1.4426950408889634f;
+#ifdef VTQ_ATTN_DIAG
+    unsigned long long dg_k0, dg_r0, dg_t, dg_p1 = 0, dg_p2 = 0, dg_bar = 0, dg_pro = 0, dg_rest = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_k0), "=s"(dg_r0) :: "memory");
+    dg_t = dg_k0;
+#endif
+
+    auto block_base = [&](int b, int& qb) __attribute__((always_inline)) -> int64_t {
+        qb = b % nqb;
+        const int head = (b / nqb) % nh, seq = b / (nqb * nh);
+        return (int64_t)seq * S_pad * ld + head * 64;
+    };
+    auto block_out = [&](int b) __attribute__((always_inline)) -> int64_t {
+        const int head = (b / nqb) % nh, seq = b / (nqb * nh);
+        return (int64_t)seq * S_pad * H + head * 64;
+    };
+    auto load_q = [&](int b, tx8 (&qf)[2][4]) __attribute__((always_inline)) {
+        int qb;
+        const int64_t base = block_base(b, qb);
+        int qr = qb * 256 + wave * 32 + c;
+        qr = qr < S_pad ? qr : S_pad - 1;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) qf[pl][t] = *(const tx8*)(qkv + pl * plane + base + (int64_t)qr * ld + 16 * t + 8 * hh);
+    };
+
+    // the same loads hidden from hipcc's vmcnt bookkeeping (in place: no copy of a register whose data has not landed); the caller
+    // waits with a counted vmcnt that names qf
+    auto load_q_async = [&](int b, tx8 (&qf)[2][4]) __attribute__((always_inline)) {
+        int qb;
+        const int64_t base = block_base(b, qb);
+        int qr = qb * 256 + wave * 32 + c;
+        qr = qr < S_pad ? qr : S_pad - 1;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const T* ptr = qkv + pl * plane + base + (int64_t)qr * ld + 16 * t + 8 * hh;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(qf[pl][t]) : "v"(ptr) : "memory");
+            }
+    };
+    auto pin_q = [&](tx8 (&qf)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(qf[pl][t]));
+    };
+
+    const int d_row = tid >> 3, d_s = tid & 7;
+    const uint32_t k_off = (uint32_t)(d_row * ld + H + ((d_s ^ ((d_row >> 1) & 7)) << 3));
+    const uint32_t v_off = (uint32_t)(d_row * ld + 2 * H + ((d_s ^ (((d_row >> 1) & 1) << 2)) << 3));
+    int ib = b0, it = 0, itau = 0, iqb;
+    int64_t ibase = block_base(ib, iqb);
+    auto issue_tile = [&]() __attribute__((always_inline)) -> bool {
+        if (ib >= b1) return false;
+        char* sb = smem + (itau & 3) * STAGE + wave * 1024;
+        const T* base = qkv + ibase + (int64_t)it * KT * ld;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            if (VTQ_SW_NODMA) break;
+            glds16(base + pl * plane + k_off, sb + pl * TB);
+            glds16(base + pl * plane + v_off, sb + (NPL + pl) * TB);
+        }
+        ++itau;
+        if (++it == nt) {
+            it = 0;
+            if (++ib < b1) ibase = block_base(ib, iqb);
+        }
+        return true;
+    };
+
+    tx8 qf[2][4];
+    load_q(b0, qf);
+    if constexpr (NSPLIT == 3) { if (!q_log2) prescale_q<T>(qf, sc); }          // scores in log2 units (see prescale_q)
+    issue_tile();
+    issue_tile();
+    issue_tile();
+
+    const uint32_t lds0 = lds_addr(smem);
+    const int k_sw = (c >> 1) & 7;
+    uint32_t k_lane[4], v_lane[2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) k_lane[tt] = lds0 + c * 128 + (((2 * tt + hh) ^ k_sw) << 4);
+    {
+        const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+        const int v_row = 4 * (g >> 1) + qq;
+        const int v_colb = ((16 * (g & 1) + 4 * pp) * 2) ^ (((qq >> 1) & 1) << 6);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) v_lane[d] = lds0 + NPL * TB + v_row * 128 + (v_colb ^ (d << 6));
+    }
+
+    f32x16 o_acc[2], sA[2], sB[2];               // sA: P of the current tile (fp32), sB: scores, then P, of the next one
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    uint32_t pfh[4][4], pfl[4][4];               // P fragments of the current tile: [step][word]
+    float m_run = -1e30f, l_run = 0.f, l_fin = 0.f;
+    float amax8 = 0.f;
+    float alpha = 1.f;
+    bool rescale = false;
+
+    int cb = b0, ct = 0, cqb;                    // block / tile-in-block of the tile whose PV runs in this iteration
+    block_base(cb, cqb);
+    bool wr_pending = false;                     // a finished block waits for its output (written in the middle of the next iteration)
+    int wr_b = 0, wr_qb = 0;
+
+    // Finished block: O / l, split into the output planes, staged through 4 KB of LDS per wave (above the ring) so that every global
+    // store instruction writes eight whole 128-byte row segments (16 B per lane) instead of 32 pieces of 8 B at the row stride.
+    // LDS image of one plane: [32 rows][8 chunks of 16 B], chunk index XORed with (row & 7); only this wave touches its region.
+    char* const o_stage = smem + 4 * STAGE + wave * 4096;
+    auto write_block = [&](float l_blk, int b, int qb) __attribute__((always_inline)) {
+        const float l_tot = l_blk + __shfl_xor(l_blk, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q_row = qb * 256 + wave * 32 + c;
+        const int64_t obase = block_out(b);
+        if (out8_scale > 0.f) {                                    // fp8 mode: bytes, direct stores (one 64-byte piece per row)
+            if (q_row < S_pad && !VTQ_SW_NOSTORE) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int dcol = 32 * d + 8 * g4 + 4 * hh;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
+                        if (q_row < S) amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
+                        *(uint32_t*)((uint8_t*)out + obase + (int64_t)q_row * H + dcol) =
+                            pack_fp8x4(v[0] * out8_scale, v[1] * out8_scale, v[2] * out8_scale, v[3] * out8_scale);
+                    }
+            }
+        } else {
+            const int r_row = lane >> 3, r_chunk = lane & 7;      // read-back: 8 lanes per row, 4 x 8 rows
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                     // chunk k = 4 d + g4 of row c, bytes 8 hh .. 8 hh + 7
+                    tx4 pv;                                       // formed per plane (the split is cheap; 32 registers of planes are not)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o_acc[k >> 2][4 * (k & 3) + e] * inv;
+                        if constexpr (NSPLIT == 1) { float u = v; asm volatile("" : "+v"(u)); pv[e] = (T)u; }   // rounded product, then converted
+                        else { T x, y; split2<T>(v, x, y); pv[e] = pl == 0 ? x : y; }
+                    }
+                    *(tx4*)(o_stage + c * 128 + ((k ^ (c & 7)) << 4) + 8 * hh) = pv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r_row + 8 * k;
+                    const uint4 w = *(const uint4*)(o_stage + row * 128 + ((r_chunk ^ (row & 7)) << 4));
+                    const int qr = qb * 256 + wave * 32 + row;
+                    if (qr < S_pad && !VTQ_SW_NOSTORE) *(uint4*)(out + pl * o_plane + obase + (int64_t)qr * H + 8 * r_chunk) = w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are done before the next plane overwrites the image
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    };
+
+    // softmax pieces on sB (tile index in its block: tb).  finish: statistics after the last exp2.
+    auto mask_tail = [&](int tb) __attribute__((always_inline)) {
+        if ((tb + 1) * KT > S) {
+            int hq = 4 * hh;
+            asm volatile("" : "+v"(hq));         // keeps the 31 key offsets of this rare path out of loop-invariant registers
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = tb * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + hq;
+                    if (key >= S) sB[kb][r] = -INFINITY;
+                }
+        }
+    };
+    float mx = 0.f, m_new = 0.f, nm = 0.f, rs = 0.f;
+    auto max_part = [&](int half) __attribute__((always_inline)) {          // half 0 / 1: the eight v_max3 of sB[half]
+        if (half == 0) mx = sB[0][0];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sB[half][r]), sB[half][r + 1]);
+        if (half == 1) {
+            // v_permlane32_swap: lanes 32..63 of the first register <-> lanes 0..31 of the second.  The second operand is an opaque
+            // copy: with the same SSA value for both, hipcc (ROCm 7.2) folded the two results into one and dropped the exchange.
+            uint32_t ma = __builtin_bit_cast(uint32_t, mx), mb = ma;
+            asm volatile("" : "+v"(mb));
+            const auto sw = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
+            uint32_t s0 = sw[0], s1 = sw[1];
+            asm volatile("" : "+v"(s0), "+v"(s1));
+            mx = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
+            m_new = fmaxf(m_run, mx);
+            nm = NSPLIT == 3 ? -m_new : -m_new * sc;     // 3-term: log2 units already
+            rs = 0.f;
+        }
+    };
+    // scores i0 .. i1 - 1 of the 32; big: |m c| > 64 somewhere in the wave -- subtract the maximum before scaling (see attention_kernel)
+    auto exp_part = [&](auto big_c, int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            float pv;
+            if constexpr (NSPLIT == 3) pv = __builtin_amdgcn_exp2f(sB[i >> 4][i & 15] - m_new);
+            else if constexpr (decltype(big_c)::value) pv = __builtin_amdgcn_exp2f((sB[i >> 4][i & 15] - m_new) * sc);
+            else pv = __builtin_amdgcn_exp2f(fmaf(sB[i >> 4][i & 15], sc, nm));
+            sB[i >> 4][i & 15] = pv;
+            rs += pv;
+        }
+        asm volatile("" : "+v"(rs));            // the slice is computed in the group it is written in
+#pragma unroll
+        for (int i = i0; i < i1; ++i) asm volatile("" : "+v"(sB[i >> 4][i & 15]));
+    };
+    auto finish_softmax = [&]() __attribute__((always_inline)) {
+        rescale = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
+        if (rescale) {
+            alpha = __builtin_amdgcn_exp2f(NSPLIT == 3 ? m_run - m_new : (m_run - m_new) * sc);
+            l_run *= alpha;
+        }
+        m_run = m_new;
+        l_run += rs;
+    };
+
+    PPFrags<T, NSPLIT> fr;
+    auto issue_k = [&](auto gc, const uint32_t (&kaddr)[4]) __attribute__((always_inline)) {       // QK^T group g = kb * 4 + tt
+        constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3, off = kb * 4096;
+        PP_DS_B128(fr.ka[sl], kaddr[tt], off);
+        if constexpr (NSPLIT == 3) PP_DS_B128(fr.kl[sl], kaddr[tt], off + TB);
+    };
+    auto issue_v = [&](auto gc, const uint32_t (&vaddr)[2]) __attribute__((always_inline)) {       // PV group g = step * 2 + d
+        constexpr int g = decltype(gc)::value, sl = (g + 8) % 3, step = g >> 1, d = g & 1, off = (step >> 1) * 4096 + (step & 1) * 2048;
+        PP_DS_TR(fr.va0[sl], vaddr[d], off);
+        PP_DS_TR(fr.va1[sl], vaddr[d], off + 1024);
+        if constexpr (NSPLIT == 3) {
+            PP_DS_TR(fr.vl0[sl], vaddr[d], off + TB);
+            PP_DS_TR(fr.vl1[sl], vaddr[d], off + TB + 1024);
+        }
+    };
+
+    // ---- pipeline prologue: S(0) = QK^T of tile 0 and its softmax, no overlap ---------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    {
+        uint32_t kaddr[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) kaddr[tt] = k_lane[tt];
+        issue_k(std::integral_constant<int, 0>{}, kaddr);
+        issue_k(std::integral_constant<int, 1>{}, kaddr);
+        static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3;
+            if constexpr (g + 2 < 8) issue_k(std::integral_constant<int, g + 2>{}, kaddr);
+            constexpr int ahead = (g + 1 < 8 ? RQK : 0) + (g + 2 < 8 ? RQK : 0);
+            if constexpr (NSPLIT == 3) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.ka[sl]), "+v"(fr.kl[sl]) : "i"(ahead));
+            else asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fr.ka[sl]) : "i"(ahead));
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const tx8 kf = __builtin_bit_cast(tx8, fr.ka[sl]);
+            sB[kb] = SW_MFMA<T>(kf, qf[0][tt], tt == 0 ? zero16 : sB[kb]);
+            if constexpr (NSPLIT == 3) {
+                const tx8 kl = __builtin_bit_cast(tx8, fr.kl[sl]);
+                sB[kb] = SW_MFMA<T>(kf, qf[1][tt], sB[kb]);
+                sB[kb] = SW_MFMA<T>(kl, qf[0][tt], sB[kb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        mask_tail(0);
+        max_part(0);
+        max_part(1);
+        if (NSPLIT != 3 && __builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) exp_part(std::true_type{}, 0, 32);
+        else exp_part(std::false_type{}, 0, 32);
+        finish_softmax();
+#pragma unroll
+        for (int d = 0; d < 2; ++d) sA[d] = sB[d];
+        if (nt == 1 && b0 + 1 < b1) {                          // single-tile blocks: the next QK^T already belongs to the next block
+            load_q_async(b0 + 1, qf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pin_q(qf);
+            if constexpr (NSPLIT == 3) { if (!q_log2) prescale_q<T>(qf, sc); }
+        }
+    }
+    VTQ_AT_SPAN(dg_pro);
+
+    auto split_half = [&](auto gc) __attribute__((always_inline)) {          // half a step of the P split: 4 probabilities of sA
+        constexpr int g = decltype(gc)::value, step = g >> 1, half = g & 1;
+        float p4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p4[j] = sA[step >> 1][8 * (step & 1) + 4 * half + j];
+        uint32_t hw[2], lw[2];
+        if constexpr (NSPLIT == 1) {
+            tx4 hv = {(T)p4[0], (T)p4[1], (T)p4[2], (T)p4[3]};
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            const u2 w = __builtin_bit_cast(u2, hv);
+            hw[0] = w[0]; hw[1] = w[1]; lw[0] = 0; lw[1] = 0;
+        } else {
+            split_p4<T>(p4, hw, lw);
+        }
+        // formed HERE (opaque), not sunk to the PV group that consumes them
+        asm volatile("" : "+v"(hw[0]), "+v"(hw[1]));
+        if constexpr (NSPLIT == 3) asm volatile("" : "+v"(lw[0]), "+v"(lw[1]));
+        pfh[step][2 * half] = hw[0]; pfh[step][2 * half + 1] = hw[1];
+        pfl[step][2 * half] = lw[0]; pfl[step][2 * half + 1] = lw[1];
+    };
+    auto iteration = [&](auto more_c, int tau) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_c)::value;         // is there a tile tau + 1 (its QK^T and softmax run in this iteration)
+        const int tb_next = (ct + 1 == nt) ? 0 : ct + 1;       // its index in its block
+        uint32_t kaddr[4], vaddr[2];
+        {
+            const uint32_t kslot = (uint32_t)((tau + 1) & 3) * STAGE, vslot = (uint32_t)(tau & 3) * STAGE;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) kaddr[tt] = k_lane[tt] + kslot;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) vaddr[d] = v_lane[d] + vslot;
+        }
+        // waves whose 32 rows lie behind the sequence in the last query block of a (sequence, head) only load and synchronise
+        const int qb_next = tb_next == 0 ? ((cqb + 1 == nqb) ? 0 : cqb + 1) : cqb;                  // query block of tile tau + 1
+        const bool active1 = (qb_next * 256 + wave * 32 < S_pad);
+        const bool active2 = (cqb * 256 + wave * 32 < S_pad);
+        // Q of the block after the one tile tau + 1 belongs to, when tile tau + 1 is that block's last: loaded into spare registers at
+        // the top of the iteration whose phase 1 still needs the current Q, installed behind the end-of-iteration wait.
+        // ---------------- phase 1: QK^T(tau + 1) -> sB  ||  split of P(tau) = sA, rescale of O ------------------------------
+        if (rescale && !wr_pending) {              // a pending block's O is written and cleared below (its successor starts from zero)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        }
+        if (!active1 && !active2) {
+        } else
+        if constexpr (more) {
+            issue_k(std::integral_constant<int, 0>{}, kaddr);
+            issue_k(std::integral_constant<int, 1>{}, kaddr);
+            static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3;
+                if constexpr (g + 2 < 8) issue_k(std::integral_constant<int, g + 2>{}, kaddr);
+                else issue_v(std::integral_constant<int, g + 2 - 8>{}, vaddr);
+                constexpr int ahead = (g + 1 < 8 ? RQK : RPV) + (g + 2 < 8 ? RQK : RPV);
+                if constexpr (NSPLIT == 3) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.ka[sl]), "+v"(fr.kl[sl]) : "i"(ahead));
+                else asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fr.ka[sl]) : "i"(ahead));
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const tx8 kf = __builtin_bit_cast(tx8, fr.ka[sl]);
+                sB[kb] = SW_MFMA<T>(kf, qf[0][tt], tt == 0 ? zero16 : sB[kb]);
+                if constexpr (NSPLIT == 3) {
+                    const tx8 kl = __builtin_bit_cast(tx8, fr.kl[sl]);
+                    sB[kb] = SW_MFMA<T>(kf, qf[1][tt], sB[kb]);
+                    sB[kb] = SW_MFMA<T>(kl, qf[0][tt], sB[kb]);
+                }
+                if constexpr (!VTQ_SW_NOFILL) split_half(gc);
+                if constexpr (NSPLIT == 3) { SW_MFMA_VALU(4); SW_MFMA_VALU(4); SW_MFMA_VALU(4); }
+                else { SW_MFMA_VALU(2); }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            // last tile of the stream: no QK^T left; split without cover, first PV fragments
+            static_for<0, 8>([&](auto gc) __attribute__((always_inline)) { split_half(gc); });
+            issue_v(std::integral_constant<int, 0>{}, vaddr);
+            issue_v(std::integral_constant<int, 1>{}, vaddr);
+        }
+        VTQ_AT_SPAN(dg_p1);
+        // output of the block that ended with the previous iteration's PV: phase 1 did not touch O; its stores are older than this
+        // iteration's LDS-DMA and have phase 2 as cover before the counted wait at the end
+        if (wr_pending) { write_block(l_fin, wr_b, wr_qb); wr_pending = false; }
+        // at a seam the finished block's row sums are set aside and the statistics restart before the next tile's softmax
+        const bool seam = (ct + 1 == nt);
+        if (seam) { l_fin = l_run; m_run = -1e30f; l_run = 0.f; }
+        if constexpr (more) mask_tail(tb_next);
+        // ---------------- phase 2: PV(tau) into O  ||  softmax of sB (tile tau + 1) -------------------------------------------
+        bool sent = false, q_loaded = false;
+        auto pv_group = [&](auto gc, auto big_c) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, sl = (g + 8) % 3, step = g >> 1, d = g & 1;
+            if constexpr (g + 2 < 8) issue_v(std::integral_constant<int, g + 2>{}, vaddr);
+            constexpr int ahead = (g + 1 < 8 ? RPV : 0) + (g + 2 < 8 ? RPV : 0);
+            if constexpr (NSPLIT == 3)
+                asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(fr.va0[sl]), "+v"(fr.va1[sl]), "+v"(fr.vl0[sl]), "+v"(fr.vl1[sl]) : "i"(ahead));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.va0[sl]), "+v"(fr.va1[sl]) : "i"(ahead));
+            __builtin_amdgcn_sched_barrier(0);
+            const tx8 vf = __builtin_bit_cast(tx8, u32x4{fr.va0[sl][0], fr.va0[sl][1], fr.va1[sl][0], fr.va1[sl][1]});
+            const tx8 ph = __builtin_bit_cast(tx8, u32x4{pfh[step][0], pfh[step][1], pfh[step][2], pfh[step][3]});
+            o_acc[d] = SW_MFMA<T>(vf, ph, o_acc[d]);
+            if constexpr (NSPLIT == 3) {
+                const tx8 vl = __builtin_bit_cast(tx8, u32x4{fr.vl0[sl][0], fr.vl0[sl][1], fr.vl1[sl][0], fr.vl1[sl][1]});
+                const tx8 pl = __builtin_bit_cast(tx8, u32x4{pfl[step][0], pfl[step][1], pfl[step][2], pfl[step][3]});
+                o_acc[d] = SW_MFMA<T>(vf, pl, o_acc[d]);
+                o_acc[d] = SW_MFMA<T>(vl, ph, o_acc[d]);
+            }
+            if constexpr (more && !VTQ_SW_NOFILL) {
+                if constexpr (g == 0) max_part(0);
+                else if constexpr (g == 1) max_part(1);
+                else if constexpr (g == 2) exp_part(big_c, 0, 6);
+                else if constexpr (g == 3) exp_part(big_c, 6, 12);
+                else if constexpr (g == 4) exp_part(big_c, 12, 17);
+                else if constexpr (g == 5) exp_part(big_c, 17, 22);
+                else if constexpr (g == 6) exp_part(big_c, 22, 27);
+                else exp_part(big_c, 27, 32);
+                if constexpr (NSPLIT == 3) { SW_MFMA_VALU(5); SW_MFMA_VALU(5); SW_MFMA_VALU(5); }
+                else { SW_MFMA_VALU(6); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto phase2 = [&]() __attribute__((always_inline)) {
+            static_for<0, 2>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
+            // single plane: the running maximum of tile tau + 1 is known, huge logits take the subtract-first exponent (wave-uniform, rare)
+            if constexpr (NSPLIT == 3) {
+                static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
+            } else {
+                if (more && __builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f))
+                    static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::true_type{}); });
+                else
+                    static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
+            }
+        };
+        // Q of the next block: its registers are free once the QK^T of this block's last tile has run (phase 1 above); phase 2 covers
+        // the loads, the end-of-iteration wait completes them.
+        // Q of the block after the one tile tau + 1 belongs to: its registers are free once the QK^T of that block's last tile has run
+        // (phase 1 above); loaded in place, hidden from hipcc's vmcnt bookkeeping, complete behind the counted wait at the end
+        if constexpr (more) {
+            const int bq = (tb_next == 0 ? cb + 1 : cb) + 1;
+            if (tb_next == nt - 1 && bq < b1 && !VTQ_SW_NOQ) { load_q_async(bq, qf); q_loaded = true; }
+        }
+        sent = issue_tile();                                    // tile tau + 3: younger than the Q loads and stores, so vmcnt(NI) below covers them
+        if (active1 || active2) phase2();
+        if constexpr (more) finish_softmax(); else rescale = false;
+        VTQ_AT_SPAN(dg_p2);
+        if (seam) {
+            wr_pending = true; wr_b = cb; wr_qb = cqb;
+            ct = 0;
+            if (++cb < b1) block_base(cb, cqb);
+        } else {
+            ++ct;
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) sA[d] = sB[d];
+        VTQ_AT_SPAN(dg_rest);
+        if (sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pin_q(qf);
+        if constexpr (NSPLIT == 3) { if (q_loaded && !q_log2) prescale_q<T>(qf, sc); }
+        pp_barrier();
+        VTQ_AT_SPAN(dg_bar);
+    };
+    for (int tau = 0; tau < NT - 1; ++tau) iteration(std::true_type{}, tau);
+    iteration(std::false_type{}, NT - 1);
+    write_block(l_fin, wr_b, wr_qb);             // the last block of the list
+    if (out8_scale > 0.f) fp8_report(obs, amax8, out8_scale);
+#ifdef VTQ_ATTN_DIAG
+    if (diag) {
+        unsigned long long dg_k1, dg_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_k1), "=s"(dg_r1) :: "memory");
+        if (lane == 0) {
+            unsigned long long* dq = diag + ((size_t)blockIdx.x * 8 + wave) * 16;
+            dq[0] = dg_k1 - dg_k0; dq[1] = dg_r1 - dg_r0; dq[2] = dg_p1; dq[3] = dg_p2; dq[4] = dg_rest; dq[5] = dg_bar; dq[6] = 1; dq[7] = NT; dq[8] = 0;
+            dq[9] = dg_pro;
+        }
+    }
+#endif
 }
 
 }  // namespace
 
 template <typename T, int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
-                              float out8_scale, Fp8Obs obs) {
+                              float out8_scale, Fp8Obs obs, bool q_log2) {
+#ifdef VTQ_ATTN_DIAG
+    static const int lds_pad = getenv("VTQ_ATTN_LDS_PAD") ? atoi(getenv("VTQ_ATTN_LDS_PAD")) : 0;   // occupancy experiments
+    const int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2) + lds_pad;
+#else
     constexpr int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2);
+#endif
     static std::mutex mu;
     static bool configured[64] = {false};          // hipFuncSetAttribute is per device
     int dev = 0;
@@ -296,19 +967,87 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
         }
     }
     const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
-    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale, obs);
+    hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale, obs,
+                       gemm_diag_buffer(), q_log2 ? 1 : 0);
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            Num num, hipStream_t s, float out8_scale, Fp8Obs obs) {
-    if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (num.terms != 1 && num.terms != 3) || num.f16 > 1) return hipErrorInvalidValue;
-    if (!num.f16) {
-        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
-        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
+// Pipelined kernel: persistent grid of at most one workgroup per CU (160 KB of LDS in the 3-term formats), `per` consecutive blocks each.
+template <typename T, int NSPLIT>
+hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
+                                 float out8_scale, Fp8Obs obs, int cus, bool q_log2) {
+    constexpr int LDS = 4 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2) + 8 * 4096;     // K/V ring + output staging
+    static std::mutex mu;
+    static bool configured[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            e = hipFuncSetAttribute((const void*)attention_sw_kernel<T, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
     }
-    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
-    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs);
+    const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
+    const int per = (nblk + cus - 1) / cus;
+    const dim3 grid((nblk + per - 1) / per), blk(512);
+    hipLaunchKernelGGL((attention_sw_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, nblk, per, out8_scale, obs,
+                       gemm_diag_buffer(), q_log2 ? 1 : 0);
+    return hipGetLastError();
+}
+
+static int g_attn_variant = -1;                 // -1: the rule below (or VTQ_ATTN_VARIANT), 0: 4-wave kernel, 1: pipelined kernel
+void attention_set_variant(int v) { g_attn_variant = v; }
+
+static int device_cus(int* cus) {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cached[dev] && hipDeviceGetAttribute(&cached[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+    *cus = cached[dev];
+    return 0;
+}
+
+// Which kernel: the pipelined one pays in the 3-term formats (profiles/r03_attention_anatomy.txt: -7 .. -17 % at the encoder's shapes; the
+// single-plane formats are equal or slower), and only when its 256-row blocks keep the CUs busy: at least 85 % of the block slots of the
+// persistent grid filled, and no more than 5 % more padded query rows than the 128-row blocks of the 4-wave kernel.
+static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
+    static const int env = getenv("VTQ_ATTN_VARIANT") ? atoi(getenv("VTQ_ATTN_VARIANT")) : -1;
+    const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
+    if (forced >= 0) return forced == 1;
+    if (terms != 3) return false;
+    const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
+    const int per = (nblk + cus - 1) / cus;
+    const bool fills = (double)nblk >= 0.85 * (double)per * cus;
+    const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 105;
+    return fills && rows_ok;
+}
+
+hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
+                            Num num, hipStream_t s, float out8_scale, Fp8Obs obs, bool q_log2) {
+    if (H % 64 || S < 1 || S > S_pad || S <= S_pad - 64 || (num.terms != 1 && num.terms != 3) || num.f16 > 1) return hipErrorInvalidValue;
+    if (q_log2 && num.terms != 3) return hipErrorInvalidValue;
+    int cus = 0;
+    if (device_cus(&cus) || cus < 1) return hipErrorInvalidDevice;
+    if (use_pipelined(nseq, S_pad, H, num.terms, cus)) {
+        if (!num.f16) {
+            if (num.terms == 1) return launch_attention_sw_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+            return launch_attention_sw_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+        }
+        if (num.terms == 1) return launch_attention_sw_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+        return launch_attention_sw_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+    }
+    if (!num.f16) {
+        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+    }
+    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
 }
 
 }  // namespace vtq

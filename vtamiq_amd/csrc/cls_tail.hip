@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
 // in flight; partial maxima / sums / outputs meet in LDS.
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ q, const T* __restrict__ qkv, int64_t plane,
-                                                            float* __restrict__ out, int S, int S_pad, int H, PlaneOut po) {
+                                                            float* __restrict__ out, int S, int S_pad, int H, PlaneOut po, int q_log2) {
     typedef typename Vec<T>::x8 tx8;
     extern __shared__ __attribute__((aligned(16))) float cls_smem[];     // [8] red | [32][64] part | [S] scores
     float* red = cls_smem;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
         sc += __shfl_xor(sc, 1, 64);
         sc += __shfl_xor(sc, 2, 64);
         sc += __shfl_xor(sc, 4, 64);
-        sc *= 0.125f;
+        if (!q_log2) sc *= 0.125f;                     // q_log2: the scale (and log2 e) came with q
         if ((tid & 7) == 0) ps[key] = sc;
         mx = fmaxf(mx, sc);
     };
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
     for (int key = tid; key < S; key += 256) {
-        const float p = expf(ps[key] - mx);
+        const float p = q_log2 ? exp2f(ps[key] - mx) : expf(ps[key] - mx);
         ps[key] = p;
         sum += p;
     }
@@ -171,7 +171,7 @@ constexpr int kClsLdsMax = 160 * 1024 - 4096;                 // leave room for 
 constexpr int kClsFixed = (8 + 32 * 64) * 4;
 template <typename T, int NPL>
 hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                  PlaneOut po, hipStream_t s) {
+                                  PlaneOut po, hipStream_t s, bool q_log2) {
     const int lds = kClsFixed + ((S + 3) & ~3) * 4;
     if (lds > 48 * 1024) {                                    // beyond the default limit: raise it once per device
         static std::mutex mu;
@@ -187,7 +187,7 @@ hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane
             configured[dev] = true;
         }
     }
-    hipLaunchKernelGGL((cls_attention_kernel<T, NPL>), dim3(H / 64, nseq), dim3(256), lds, s, q, (const T*)qkv, plane, out, S, S_pad, H, po);
+    hipLaunchKernelGGL((cls_attention_kernel<T, NPL>), dim3(H / 64, nseq), dim3(256), lds, s, q, (const T*)qkv, plane, out, S, S_pad, H, po, q_log2 ? 1 : 0);
     return hipGetLastError();
 }
 }  // namespace
@@ -195,12 +195,12 @@ hipError_t launch_cls_attention_t(const float* q, const void* qkv, int64_t plane
 int cls_attention_max_seq() { return (kClsLdsMax - kClsFixed) / 4; }
 
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int f16_, int planes, PlaneOut po, hipStream_t s) {
+                                int f16_, int planes, PlaneOut po, hipStream_t s, bool q_log2) {
     if (S < 1 || S > cls_attention_max_seq() || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
-    if (!f16_) return planes == 1 ? launch_cls_attention_t<bf16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s)
-                                  : launch_cls_attention_t<bf16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s);
-    return planes == 1 ? launch_cls_attention_t<f16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s)
-                       : launch_cls_attention_t<f16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s);
+    if (!f16_) return planes == 1 ? launch_cls_attention_t<bf16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s, q_log2)
+                                  : launch_cls_attention_t<bf16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s, q_log2);
+    return planes == 1 ? launch_cls_attention_t<f16, 1>(q, qkv, plane, out, nseq, S, S_pad, H, po, s, q_log2)
+                       : launch_cls_attention_t<f16, 2>(q, qkv, plane, out, nseq, S, S_pad, H, po, s, q_log2);
 }
 
 }  // namespace vtq

@@ -284,6 +284,15 @@ hipError_t launch_split_rows_pad(const float* src, void* dst, int64_t plane, int
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float mul) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i] * mul;
+}
+
+hipError_t launch_scale_copy(const float* src, float* dst, int64_t n, float mul, hipStream_t s) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n, mul);
+    return hipGetLastError();
+}
+
 hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16_, int planes, hipStream_t s, float scale, Fp8Obs obs) {
     if (numel % 4) return hipErrorInvalidValue;
     const int64_t n4 = numel / 4;

@@ -54,6 +54,11 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 constexpr float kSPatch = 256.0f, kSLn = 8.0f, kSAtt = 16.0f, kSGelu = 4.0f;
 constexpr float kFp8Target = 224.0f;
 
+// Softmax scale of MultiHeadSelfAttention (transformer.py:158-160: scores / sqrt(head_dim), head_dim = 64) times log2(e): with the
+// 3-term attention the engine folds it into the query projection at weight ingestion, so that scores arrive in log2 units and the
+// kernels' exponent is exp2(s - max) -- a subtraction that is exact for the row maximum at any magnitude (attention.hip prescale_q).
+constexpr float kQLog2Scale = 0.125f * 1.4426950408889634f;
+
 struct Slot {
     void* dst = nullptr;      // destination (fp32 copy) or bf16 hi plane (split)
     int64_t numel = 0;
@@ -62,6 +67,7 @@ struct Slot {
     float* scale = nullptr;   // fp8 mode: destination of the rows' inverse scales
     int64_t K = 0;            // row length of a split tensor
     int64_t Kp = 0;           // row pitch of its packed planes (> K: zero-padded to the GEMM's K tile; 0 = K)
+    float mul = 1.0f;         // the tensor is multiplied by this on ingestion (query projection: kQLog2Scale)
     bool ignore = false;      // accepted and dropped: a parameter the forward never reads (adapter pairs other than pair 0)
     bool loaded = false;
 };
@@ -204,6 +210,10 @@ int build(vtq_engine* e) {
             add_split(e, p + "attn." + qkvn[j] + ".weight", L.wqkv, L.pqkv, j * H, H, H, L.sqkv);
             Slot s; s.dst = L.bqkv + j * H; s.numel = H;
             e->slots[p + "attn." + qkvn[j] + ".bias"] = s;
+        }
+        if (e->att.terms == 3) {       // 3-term attention takes Q in log2 units: (x W_q + b_q) * kQLog2Scale, folded into W_q and b_q
+            e->slots[p + "attn.query.weight"].mul = kQLog2Scale;
+            e->slots[p + "attn.query.bias"].mul = kQLog2Scale;
         }
         add_split(e, p + "attn.out.weight", L.wo, L.po, 0, H, H, L.so);
         add_split(e, p + "ffn.fc1.weight", L.w1, L.p1, 0, M, H, L.s1);
@@ -477,7 +487,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
                     a.epi = SK_PLAIN; a.y = qcls; a.ldy = H; a.ycols = H;
                     HIP_TRY(launch_skinny(a, lin, s));
                 }
-                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, nullptr, R, g.S, g.S_pad, H, f16, apl, tl, s));
+                HIP_TRY(launch_cls_attention(qcls, big, e->big_plane, nullptr, R, g.S, g.S_pad, H, f16, apl, tl, s, e->att.terms == 3));
                 {   // out-proj + LayerScale + residual, in place on the CLS rows
                     SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wo, Ly.po, H, H, Ly.bo);
                     a.epi = SK_RESID; a.gamma = Ly.g1; a.res = xcls; a.ldr = H; a.y = xcls; a.ldy = H; a.ycols = H;
@@ -535,8 +545,8 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
         {
             Prof p(e, s, VTQ_K_ATTN);
             if (f8m) {
-                if (fp8_stage(e, s, e->s_att[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, sc, ob)); return 0; })) return 1;
-            } else HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s));
+                if (fp8_stage(e, s, e->s_att[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, sc, ob, e->att.terms == 3)); return 0; })) return 1;
+            } else HIP_TRY(launch_attention(big, e->big_plane, lnb, e->ln_plane, g.nseq, g.S, g.S_pad, H, e->att, s, 0.0f, Fp8Obs{nullptr, nullptr}, e->att.terms == 3));
         }
         if (e->dbg_stop == i * 7 + 2) return 0;
         {
@@ -737,6 +747,9 @@ void vtq_destroy(vtq_handle e) {
 int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void* stream) {
     if (!e || !descs) return fail("vtq_load_weights: null argument");
     hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;                                  // one buffer for the scaled copies, reused in stream order
+    int64_t scratch_n = 0;
+    struct Free { float*& p; ~Free() { if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); } } } free_scratch{scratch};
     for (int i = 0; i < n; ++i) {
         const vtq_tensor_desc& d = descs[i];
         if (!d.name || !d.data) return fail("vtq_load_weights: descriptor %d has a null field", i);
@@ -745,11 +758,22 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
         Slot& sl = it->second;
         if (sl.numel != d.numel) return fail("vtq_load_weights: '%s' has %lld elements, expected %lld", d.name, (long long)d.numel, (long long)sl.numel);
         if (sl.ignore) { sl.loaded = true; continue; }
-        if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(d.data, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s, (int)sl.Kp));
+        const float* src = (const float*)d.data;
+        if (sl.mul != 1.0f) {                                   // scaled copy first (query projection, 3-term attention)
+            if (scratch_n < sl.numel) {
+                if (scratch) (void)hipFree(scratch);
+                scratch = nullptr;
+                HIP_TRY(hipMalloc((void**)&scratch, (size_t)sl.numel * 4));
+                scratch_n = sl.numel;
+            }
+            HIP_TRY(launch_scale_copy(src, scratch, sl.numel, sl.mul, s));
+            src = scratch;
+        }
+        if (sl.split && e->fp8) HIP_TRY(launch_quant_rows_fp8(src, sl.dst, sl.scale, (int)(sl.numel / sl.K), (int)sl.K, s, (int)sl.Kp));
         else if (sl.split && sl.Kp != sl.K)
-            HIP_TRY(launch_split_rows_pad(d.data, sl.dst, sl.plane, (int)(sl.numel / sl.K), (int)sl.K, (int)sl.Kp, e->f16, e->wpl, s));
-        else if (sl.split) HIP_TRY(launch_split(d.data, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
-        else HIP_TRY(hipMemcpyAsync(sl.dst, d.data, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(launch_split_rows_pad(src, sl.dst, sl.plane, (int)(sl.numel / sl.K), (int)sl.K, (int)sl.Kp, e->f16, e->wpl, s));
+        else if (sl.split) HIP_TRY(launch_split(src, sl.dst, sl.plane, sl.numel, e->f16, e->wpl, s));
+        else HIP_TRY(hipMemcpyAsync(sl.dst, src, (size_t)sl.numel * 4, hipMemcpyDeviceToDevice, s));
         sl.loaded = true;
     }
     if (pack_head(e, s)) return 1;
@@ -782,6 +806,11 @@ int vtq_debug_buffers(vtq_handle e, void** x, void** lnbuf, void** big, int64_t*
     if (lnbuf) *lnbuf = e->lnbuf;
     if (big) *big = e->big;
     if (rows) *rows = e->ln_plane / e->H;
+    return 0;
+}
+
+int vtq_debug_attention_variant(int32_t v) {
+    attention_set_variant(v);
     return 0;
 }
 

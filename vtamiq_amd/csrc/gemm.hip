@@ -961,6 +961,7 @@ template <typename T, int TERMS> hipError_t launch_e(const GemmArgs& a, int epil
 }  // namespace
 
 void gemm_set_diag(unsigned long long* buf, int shadow) { g_diag_buf = buf; g_diag_shadow = shadow; }
+unsigned long long* gemm_diag_buffer() { return g_diag_buf; }
 bool gemm_is_diag_build() {
 #ifdef VTQ_GEMM_DIAG
     return true;

@@ -72,6 +72,8 @@ struct GemmArgs {
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
+void attention_set_variant(int v);               // test / measurement hook: -1 default, 0 four-wave kernel, 1 ping-pong kernel
+unsigned long long* gemm_diag_buffer();         // the buffer of gemm_set_diag (attention's diagnostic build shares it)
 void gemm_set_diag(unsigned long long* buf, int shadow);
 bool gemm_is_diag_build();
 // Build and upload (async on s) the persistent tile schedule of an (M, N, K) GEMM with wpl weight planes on the current device, if
@@ -85,6 +87,8 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl);
 // f16 == 2: e4m3 bytes of value * scale
 hipError_t launch_split(const float* src, void* dst, int64_t plane, int64_t numel, int f16, int planes, hipStream_t s, float scale = 1.0f,
                         Fp8Obs obs = Fp8Obs{nullptr, nullptr});
+// dst[i] = src[i] * mul (weight ingestion: the softmax scale folded into the query projection, engine.hip kQLog2Scale)
+hipError_t launch_scale_copy(const float* src, float* dst, int64_t n, float mul, hipStream_t s);
 // fp8 weights: W[N][K] fp32 -> e4m3 rows with a per-row power-of-two scale; inv_scale[n] = 1 / scale
 hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s, int Kp = 0);
 // rows of K floats -> planes with row pitch Kp >= K, zero beyond K
@@ -108,8 +112,10 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, void
 
 // num.terms: 1 = single planes, 3 = hi/lo planes for Q, K, V and P (the 2-term form is not offered: DESIGN.md section 2)
 // out8_scale > 0: the output is written as e4m3 bytes of value * out8_scale ([rows][H] bytes) instead of planes (fp8 mode)
+// q_log2 (3-term formats only): Q already carries the softmax scale 1/sqrt(64) * log2(e) (the engine folds it into the query
+// projection's weights); otherwise the kernels fold it into their Q fragments themselves (attention.hip prescale_q)
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
-                            Num num, hipStream_t s, float out8_scale = 0.0f, Fp8Obs obs = Fp8Obs{nullptr, nullptr});
+                            Num num, hipStream_t s, float out8_scale = 0.0f, Fp8Obs obs = Fp8Obs{nullptr, nullptr}, bool q_log2 = false);
 
 // zero the rows of the residual stream that belong to no token: per-sequence pads, per-part tails, and everything up to rows_total
 hipError_t launch_zero_pad_rows(float* x, int nseq, int S, SeqMap sm, int H, int rows_total, hipStream_t s);
@@ -153,8 +159,9 @@ hipError_t launch_rows_to_planes(const float* x, int ldx, const float* slope, vo
 hipError_t launch_rows_ln(const float* src, int64_t stride, const float* w, const float* b, float* ln, float* copy, int rows, int H,
                           PlaneOut po, hipStream_t s);
 // K, V rows of the packed qkv planes (f16, planes); any S (the score buffer is dynamic LDS)
+// q_log2: q already carries 1/sqrt(64) * log2(e) (see launch_attention)
 hipError_t launch_cls_attention(const float* q, const void* qkv, int64_t plane, float* out, int nseq, int S, int S_pad, int H,
-                                int f16, int planes, PlaneOut po, hipStream_t s);
+                                int f16, int planes, PlaneOut po, hipStream_t s, bool q_log2 = false);
 // largest S launch_cls_attention accepts (LDS score buffer); longer sequences run the full last layer instead
 int cls_attention_max_seq();
 
