@@ -210,11 +210,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         VTQ_AT_SPAN(dg_qk);
         // ---- online softmax (base-2 domain; scale folded into one FMA per score) -----------------------------------
         if ((t + 1) * KT > S) {                 // wave-uniform: only the last tile(s) hold padded keys
+            int hq = 4 * hh;
+            asm volatile("" : "+v"(hq));         // keeps the 31 key offsets of this rare path out of loop-invariant registers
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + hq;
                     if (key >= S) sacc[kb][r] = -INFINITY;
                 }
         }
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[kb][r]), sacc[kb][r + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                                              // running max (3-term: log2 units; else raw)
-        const float nm = -m_new * sc;
+        float nm = -m_new * sc;
         float rs = 0.f;
         if constexpr (NSPLIT == 3) {
 #pragma unroll
@@ -236,20 +238,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                     sacc[kb][r] = pv;
                     rs += pv;
                 }
-        } else
-        // single plane: exp2(s c - m c) as ONE FMA per score is exact enough only while |m c| is small: the FMA subtracts the ROUNDED
-        // product m c, so the maximum's own exponent is the rounding error of m c (2^-24 |m c|) instead of 0 -- harmless at |m c| <= 64
-        // (3e-6), inf at the logits of a 1e7-gain model (the fp32 reference returns finite scores there).  Beyond 64: subtract first.
-        if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f((sacc[kb][r] - m_new) * sc);
-                    sacc[kb][r] = pv;
-                    rs += pv;
-                }
         } else {
+            // single plane: exp2(s c - m c) as ONE FMA per score is exact enough only while |m c| is small: the FMA subtracts the ROUNDED
+            // product m c, so the maximum's own exponent is the rounding error of m c (2^-24 |m c|) instead of 0 -- harmless at
+            // |m c| <= 64 (3e-6), inf at the logits of a 1e7-gain model (the fp32 reference returns finite scores there).  Beyond 64
+            // (wave-uniform, rare): subtract the maximum first, then the same FMA with a zero addend.
+            if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= m_new;
+                nm = 0.f;
+            }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -680,15 +680,22 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             m_new = fmaxf(m_run, mx);
             nm = NSPLIT == 3 ? -m_new : -m_new * sc;     // 3-term: log2 units already
             rs = 0.f;
+            if constexpr (NSPLIT != 3) {                 // huge logits (wave-uniform, rare): subtract first, see attention_kernel
+                if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sB[kb][r] -= m_new;
+                    nm = 0.f;
+                }
+            }
         }
     };
-    // scores i0 .. i1 - 1 of the 32; big: |m c| > 64 somewhere in the wave -- subtract the maximum before scaling (see attention_kernel)
-    auto exp_part = [&](auto big_c, int i0, int i1) __attribute__((always_inline)) {
+    auto exp_part = [&](int i0, int i1) __attribute__((always_inline)) {    // scores i0 .. i1 - 1 of the 32
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             float pv;
             if constexpr (NSPLIT == 3) pv = __builtin_amdgcn_exp2f(sB[i >> 4][i & 15] - m_new);
-            else if constexpr (decltype(big_c)::value) pv = __builtin_amdgcn_exp2f((sB[i >> 4][i & 15] - m_new) * sc);
             else pv = __builtin_amdgcn_exp2f(fmaf(sB[i >> 4][i & 15], sc, nm));
             sB[i >> 4][i & 15] = pv;
             rs += pv;
@@ -751,8 +758,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         mask_tail(0);
         max_part(0);
         max_part(1);
-        if (NSPLIT != 3 && __builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) exp_part(std::true_type{}, 0, 32);
-        else exp_part(std::false_type{}, 0, 32);
+        exp_part(0, 32);
         finish_softmax();
 #pragma unroll
         for (int d = 0; d < 2; ++d) sA[d] = sB[d];
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if constexpr (more) mask_tail(tb_next);
         // ---------------- phase 2: PV(tau) into O  ||  softmax of sB (tile tau + 1) -------------------------------------------
         bool sent = false, q_loaded = false;
-        auto pv_group = [&](auto gc, auto big_c) __attribute__((always_inline)) {
+        auto pv_group = [&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value, sl = (g + 8) % 3, step = g >> 1, d = g & 1;
             if constexpr (g + 2 < 8) issue_v(std::integral_constant<int, g + 2>{}, vaddr);
             constexpr int ahead = (g + 1 < 8 ? RPV : 0) + (g + 2 < 8 ? RPV : 0);
@@ -872,29 +878,18 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             if constexpr (more && !VTQ_SW_NOFILL) {
                 if constexpr (g == 0) max_part(0);
                 else if constexpr (g == 1) max_part(1);
-                else if constexpr (g == 2) exp_part(big_c, 0, 6);
-                else if constexpr (g == 3) exp_part(big_c, 6, 12);
-                else if constexpr (g == 4) exp_part(big_c, 12, 17);
-                else if constexpr (g == 5) exp_part(big_c, 17, 22);
-                else if constexpr (g == 6) exp_part(big_c, 22, 27);
-                else exp_part(big_c, 27, 32);
+                else if constexpr (g == 2) exp_part(0, 6);
+                else if constexpr (g == 3) exp_part(6, 12);
+                else if constexpr (g == 4) exp_part(12, 17);
+                else if constexpr (g == 5) exp_part(17, 22);
+                else if constexpr (g == 6) exp_part(22, 27);
+                else exp_part(27, 32);
                 if constexpr (NSPLIT == 3) { SW_MFMA_VALU(5); SW_MFMA_VALU(5); SW_MFMA_VALU(5); }
                 else { SW_MFMA_VALU(6); }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto phase2 = [&]() __attribute__((always_inline)) {
-            static_for<0, 2>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
-            // single plane: the running maximum of tile tau + 1 is known, huge logits take the subtract-first exponent (wave-uniform, rare)
-            if constexpr (NSPLIT == 3) {
-                static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
-            } else {
-                if (more && __builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f))
-                    static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::true_type{}); });
-                else
-                    static_for<2, 8>([&](auto gc) __attribute__((always_inline)) { pv_group(gc, std::false_type{}); });
-            }
-        };
+        auto phase2 = [&]() __attribute__((always_inline)) { static_for<0, 8>(pv_group); };
         // Q of the next block: its registers are free once the QK^T of this block's last tile has run (phase 1 above); phase 2 covers
         // the loads, the end-of-iteration wait completes them.
         // Q of the block after the one tile tau + 1 belongs to: its registers are free once the QK^T of that block's last tile has run
