@@ -509,6 +509,33 @@ def test_default_model_has_no_silent_nans():
         auto(p, oob, sc)
 
 
+@pytest.mark.parametrize("name,precision", [("c2shape_b4_n500", "fp16x3"), ("vitl_b2_n70", "fp16x3"), ("scales3_b2_n40", "bf16x3"),
+                                            ("refdefault_b2_n64", "fp16x2"), ("c2shape_b4_n500", "fp16")])
+def test_attention_kernels_agree_end_to_end(name, precision):
+    """The engine's own rule sends small batches to the 4-wave attention kernel and chip-filling ones to the software-pipelined kernel
+    (attention.hip use_pipelined); forced either way the scores of a forward are the same bits -- on goldens with extra tokens, three
+    scales, ViT-L and the single-plane format the rule never gives to the pipelined kernel -- and 12 repeated forwards through the
+    pipelined kernel (persistent workgroups, LDS ring, counted waits: a race would show) repeat bit for bit."""
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    got = []
+    for variant in (0, 1):
+        lib.vtq_debug_attention_variant(variant)
+        try:
+            model = build(kw, sd, precision)
+            with torch.no_grad():
+                q = model(p, ps, sc)[0]
+                for _ in range(12 if variant == 1 else 1):
+                    assert torch.equal(model(p, ps, sc)[0], q)
+            got.append(q.cpu().numpy())
+        finally:
+            lib.vtq_debug_attention_variant(-1)
+    assert np.array_equal(got[0], got[1])
+    assert gate(got[1], g["q"], TOL[precision]), rel_err(got[1], g["q"])
+
+
 @pytest.mark.parametrize("precision", ["fp16x3", "fp16", "fp8"])
 def test_repeated_forwards_are_bitwise_identical(precision):
     """Race detector for the persistent GEMM (DMA ring chained across tile boundaries, counted vmcnt, raw barriers) and every other

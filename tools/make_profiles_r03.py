@@ -109,8 +109,10 @@ write("r03_gemm_fc1_traffic.json", json.dumps(js, indent=1))
 ta = pmc_table("attn_pmc", "attention")
 at = ["# command: rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES",
       "#          SQ_WAIT_INST_ANY --kernel-trace -- python3 tools/attn_bench.py --fmt fp16x3 fp16   (64 sequences x 501 tokens x 12 heads x 64: the encoder shape at B=32)",
-      "# The attention kernel is the round-2 kernel (the round's experiments on it -- cheaper P split, start stagger, two query blocks per wave -- did not pay:",
-      "# profiles/r03_valu_diet_ab.txt, r03_attention_qb2.txt).", "",
+      "# The library's rule picks the software-pipelined kernel for the 3-term format at this shape and the 4-wave kernel for the single-plane one",
+      "# (profiles/r03_attention_anatomy.txt; round 2's counters of the 4-wave kernel in fp16x3: r02_attention_pmc.txt, MFMA busy 40 %, 7.5 VALU per MFMA).",
+      "# The pipelined kernel's LDS bank conflicts are the 8-byte writes of its output staging (4-way, once per query block).",
+      "# The unprofiled times at the end are short bursts of 5 launches from idle (tools/attn_bench.py); sustained: tools/attn_probe.py.", "",
       cap(SP.pmc, os.path.join(G, "attn_pmc"), "attention"), "# derived: cycles/XCD = GRBM_GUI_ACTIVE / 8; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x cycles)"]
 for k, v in ta.items():
     cyc = v["GRBM_GUI_ACTIVE"] / 8

@@ -1010,7 +1010,9 @@ static int device_cus(int* cus) {
 
 // Which kernel: the pipelined one pays in the 3-term formats (profiles/r03_attention_anatomy.txt: -7 .. -17 % at the encoder's shapes; the
 // single-plane formats are equal or slower), and only when its 256-row blocks keep the CUs busy: at least 85 % of the block slots of the
-// persistent grid filled, and no more than 5 % more padded query rows than the 128-row blocks of the 4-wave kernel.
+// persistent grid filled, and no more than 15 % more padded query rows than the 128-row blocks of the 4-wave kernel (waves without rows
+// skip their arithmetic, so padding costs the skeleton only: S = 1025 pads 11 % more rows and is 6 % faster; S = 257 pads 33 % more
+// and is 34 % slower).
 static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
     static const int env = getenv("VTQ_ATTN_VARIANT") ? atoi(getenv("VTQ_ATTN_VARIANT")) : -1;
     const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
@@ -1019,7 +1021,7 @@ static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
     const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
     const int per = (nblk + cus - 1) / cus;
     const bool fills = (double)nblk >= 0.85 * (double)per * cus;
-    const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 105;
+    const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 115;
     return fills && rows_ok;
 }
 
