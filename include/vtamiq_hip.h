@@ -153,6 +153,9 @@ int  vtq_debug_gemm_diag(void* buf, int32_t shadow);
  * formats when its 256-row blocks fill the chip; environment VTQ_ATTN_VARIANT overrides the rule).  Both compute the same arithmetic
  * in the same order per query row: outputs are bit-identical. */
 int  vtq_debug_attention_variant(int32_t variant);
+/* Host-only: which kernel the library's rule gives nseq sequences of pitch S_pad, hidden size H, operand format num (VTQ_NUM_*) on a
+ * device with `cus` compute units: 1 = pipelined, 0 = 4-wave, -1 = bad format code. */
+int  vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
 #define VTQ_K_CONVERT  0

@@ -125,6 +125,25 @@ def test_predict_pairwise_branch_matches_reference_semantics():
     assert torch.allclose(q_p2, torch.sigmoid(q1 - q2))
 
 
+def test_attention_kernel_rule():
+    """Which fused-attention kernel launch_attention picks (attention.hip attention_rule; pure host code): the persistent pipelined
+    kernel only for the 3-term formats, only when its 256-row blocks fill >= 85 % of the slots of the persistent grid and pad <= 15 %
+    more query rows than 128-row blocks would -- the shapes of profiles/r03_attention_anatomy.txt on a 256-CU device."""
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    rule = lambda nseq, S, H, fmt, cus=256: lib.vtq_k_attention_rule(nseq, S, H, _lib.NUM[fmt], cus)
+    assert rule(64, 501, 768, "fp16x3") == 1 and rule(64, 501, 768, "bf16x3") == 1          # BASELINE configs[1], B = 32
+    assert rule(64, 501, 768, "fp16") == 0 and rule(64, 501, 768, "bf16") == 0              # single-plane formats: 4-wave kernel
+    assert rule(32, 1025, 1024, "fp16x3") == 1                                              # configs[3]: one valid row in the 5th block, 11 % padding
+    assert rule(8, 2501, 768, "fp16x3") == 1                                                # N = 2500: 960 blocks = 3.75 per CU
+    assert rule(2, 257, 768, "fp16x3") == 0 and rule(64, 257, 768, "fp16x3") == 0           # 33 % more padded rows
+    assert rule(4, 300, 768, "fp16x3") == 0 and rule(3, 51, 768, "fp16x3") == 0             # grids that leave CUs idle
+    assert rule(8, 501, 768, "fp16x3") == 0 and rule(10, 501, 768, "fp16x3") == 1           # 192 / 240 blocks of 256 slots
+    assert rule(14, 501, 768, "fp16x3") == 0 and rule(19, 501, 768, "fp16x3") == 1          # 336 of 512 slots: 66 %; 456: 89 %
+    assert rule(76, 501, 768, "fp16x3", cus=304) == 1 and rule(64, 501, 768, "fp16x3", cus=304) == 0   # 1824 = 6 x 304; 1536 of 1824 slots: 84 %
+    assert rule(64, 501, 768, "fp16x2") == 0 and rule(64, 501, 768, "fp8") in (0, -1)       # no 2-term attention (the fp16x2 ENGINE mode runs fp16x3 attention)
+
+
 def test_gemm_tile_schedule_covers_every_tile_once():
     """The host-built persistent schedule of the GEMM (gemm.hip build_schedule): 256 per-workgroup lists; every 256x256 tile
     appears exactly once, either whole or as its top AND bottom half; half tiles only close a list; lists are balanced; pure

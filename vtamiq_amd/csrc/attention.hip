@@ -1013,16 +1013,20 @@ static int device_cus(int* cus) {
 // persistent grid filled, and no more than 15 % more padded query rows than the 128-row blocks of the 4-wave kernel (waves without rows
 // skip their arithmetic, so padding costs the skeleton only: S = 1025 pads 11 % more rows and is 6 % faster; S = 257 pads 33 % more
 // and is 34 % slower).
-static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
-    static const int env = getenv("VTQ_ATTN_VARIANT") ? atoi(getenv("VTQ_ATTN_VARIANT")) : -1;
-    const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
-    if (forced >= 0) return forced == 1;
-    if (terms != 3) return false;
+bool attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
+    if (terms != 3 || cus < 1 || nseq < 1 || S_pad < 1 || H % 64) return false;
     const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
     const int per = (nblk + cus - 1) / cus;
     const bool fills = (double)nblk >= 0.85 * (double)per * cus;
     const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 115;
     return fills && rows_ok;
+}
+
+static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
+    static const int env = getenv("VTQ_ATTN_VARIANT") ? atoi(getenv("VTQ_ATTN_VARIANT")) : -1;
+    const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
+    if (forced >= 0) return forced == 1;
+    return attention_rule(nseq, S_pad, H, terms, cus);
 }
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,

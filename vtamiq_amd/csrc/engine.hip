@@ -814,6 +814,12 @@ int vtq_debug_attention_variant(int32_t v) {
     return 0;
 }
 
+int vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus) {
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm)) return -1;
+    return attention_rule(nseq, S_pad, H, nm.terms, cus) ? 1 : 0;
+}
+
 int vtq_debug_gemm_diag(void* buf, int32_t shadow) {
     gemm_set_diag((unsigned long long*)buf, shadow);
     return gemm_is_diag_build() ? 1 : 0;
