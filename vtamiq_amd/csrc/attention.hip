@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
-    uint32_t pfh[4][4], pfl[4][4];               // P fragments of the current tile: [step][word]
+    uint32_t lw_keep[2] = {0, 0};                // lo words of a half step, carried to the group that has room for them (split_half)
     float m_run = -1e30f, l_run = 0.f, l_fin = 0.f;
     float amax8 = 0.f;
     float alpha = 1.f;
@@ -771,11 +771,15 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     }
     VTQ_AT_SPAN(dg_pro);
 
-    auto split_half = [&](auto gc) __attribute__((always_inline)) {          // half a step of the P split: 4 probabilities of sA
-        constexpr int g = decltype(gc)::value, step = g >> 1, half = g & 1;
+    // Half a step of the P split: 4 probabilities of sA -> 2 hi words + 2 lo words, written IN PLACE over the floats they came from, so
+    // that after both halves the 8 registers of a step hold [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] = the two MFMA fragments of the step
+    // (no second set of 32 fragment registers).  Half 0 may only overwrite the floats it consumed (0..3): its hi words go to 0, 1 and
+    // its lo words wait in lw_keep; half 1 consumes floats 4..7 first and then fills 2, 3 (hi), 4, 5 (the kept lo) and 6, 7 (lo).
+    auto split_half = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, step = g >> 1, half = g & 1, kb = step >> 1, base = 8 * (step & 1);
         float p4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p4[j] = sA[step >> 1][8 * (step & 1) + 4 * half + j];
+        for (int j = 0; j < 4; ++j) p4[j] = sA[kb][base + 4 * half + j];
         uint32_t hw[2], lw[2];
         if constexpr (NSPLIT == 1) {
             tx4 hv = {(T)p4[0], (T)p4[1], (T)p4[2], (T)p4[3]};
@@ -788,8 +792,22 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         // formed HERE (opaque), not sunk to the PV group that consumes them
         asm volatile("" : "+v"(hw[0]), "+v"(hw[1]));
         if constexpr (NSPLIT == 3) asm volatile("" : "+v"(lw[0]), "+v"(lw[1]));
-        pfh[step][2 * half] = hw[0]; pfh[step][2 * half + 1] = hw[1];
-        pfl[step][2 * half] = lw[0]; pfl[step][2 * half + 1] = lw[1];
+        auto put = [&](int i, uint32_t w) __attribute__((always_inline)) { sA[kb][base + i] = __builtin_bit_cast(float, w); };
+        if constexpr (half == 0) {
+            put(0, hw[0]); put(1, hw[1]);
+            lw_keep[0] = lw[0]; lw_keep[1] = lw[1];
+        } else {
+            put(2, hw[0]); put(3, hw[1]);
+            if constexpr (NSPLIT == 3) { put(4, lw_keep[0]); put(5, lw_keep[1]); put(6, lw[0]); put(7, lw[1]); }
+        }
+    };
+    // the fragments of step (kb * 2 + s2): registers 8 s2 .. + 3 (hi) and + 4 .. + 7 (lo) of sA[kb]
+    auto p_frag = [&](int step, int lo) __attribute__((always_inline)) -> tx8 {
+        const f32x16& v = sA[step >> 1];
+        const int o = 8 * (step & 1) + 4 * lo;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 w = {v[o], v[o + 1], v[o + 2], v[o + 3]};
+        return __builtin_bit_cast(tx8, w);
     };
     auto iteration = [&](auto more_c, int tau) __attribute__((always_inline)) {
         constexpr bool more = decltype(more_c)::value;         // is there a tile tau + 1 (its QK^T and softmax run in this iteration)
@@ -867,11 +885,11 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
                 asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.va0[sl]), "+v"(fr.va1[sl]) : "i"(ahead));
             __builtin_amdgcn_sched_barrier(0);
             const tx8 vf = __builtin_bit_cast(tx8, u32x4{fr.va0[sl][0], fr.va0[sl][1], fr.va1[sl][0], fr.va1[sl][1]});
-            const tx8 ph = __builtin_bit_cast(tx8, u32x4{pfh[step][0], pfh[step][1], pfh[step][2], pfh[step][3]});
+            const tx8 ph = p_frag(step, 0);
             o_acc[d] = SW_MFMA<T>(vf, ph, o_acc[d]);
             if constexpr (NSPLIT == 3) {
                 const tx8 vl = __builtin_bit_cast(tx8, u32x4{fr.vl0[sl][0], fr.vl0[sl][1], fr.vl1[sl][0], fr.vl1[sl][1]});
-                const tx8 pl = __builtin_bit_cast(tx8, u32x4{pfl[step][0], pfl[step][1], pfl[step][2], pfl[step][3]});
+                const tx8 pl = p_frag(step, 1);
                 o_acc[d] = SW_MFMA<T>(vf, pl, o_acc[d]);
                 o_acc[d] = SW_MFMA<T>(vl, ph, o_acc[d]);
             }
