@@ -385,9 +385,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define PP_DS_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(addr), "i"(off))
 
 template <typename T, int NSPLIT>
-struct PPFrags {                      // three rolling fragment buffers: group g uses slot g % 3
-    u32x4 ka[3], kl[3];               // QK^T groups: K fragment hi / lo (ds_read_b128)
-    u32x2 va0[3], va1[3], vl0[3], vl1[3];   // PV groups: V^T fragment halves hi / lo (ds_read_b64_tr_b16)
+#ifndef VTQ_SW_DIST
+#define VTQ_SW_DIST 2                 // LDS fragment groups read ahead of the MFMAs that consume them (2 or 3; 3 measured: see the profile)
+#endif
+struct PPFrags {                      // DIST + 1 rolling fragment buffers: group G (QK^T 0..7, PV 8..15 of a tile) uses slot G % (DIST + 1)
+    u32x4 ka[VTQ_SW_DIST + 1], kl[VTQ_SW_DIST + 1];               // QK^T groups: K fragment hi / lo (ds_read_b128)
+    u32x2 va0[VTQ_SW_DIST + 1], va1[VTQ_SW_DIST + 1], vl0[VTQ_SW_DIST + 1], vl1[VTQ_SW_DIST + 1];   // PV groups: V^T fragment halves (ds_read_b64_tr_b16)
 };
 
 // =====================================================================================================================
@@ -464,6 +467,18 @@ __device__ __forceinline__ void split_p4(const float (&p)[4], uint32_t (&hw)[2],
     }
 }
 
+// LDS reads of fragment group G of a tile (QK^T groups 0..7: K hi [+ lo] by ds_read_b128; PV groups 8..15: V^T hi [+ lo] by two
+// ds_read_b64_tr_b16 each), and the reads still in flight when group G is consumed: those of the next VTQ_SW_DIST groups below `end`
+template <int NSPLIT>
+constexpr int sw_reads(int G) { return G < 8 ? (NSPLIT == 1 ? 1 : 2) : (G < 16 ? (NSPLIT == 1 ? 2 : 4) : 0); }
+template <int NSPLIT>
+constexpr int sw_ahead(int G, int end) {
+    int n = 0;
+    for (int j = 1; j <= VTQ_SW_DIST; ++j)
+        if (G + j < end) n += sw_reads<NSPLIT>(G + j);
+    return n;
+}
+
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out, int64_t o_plane,
                                                            int S, int S_pad, int H, int nblk, int per, float out8_scale, Fp8Obs obs,
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
     constexpr int KT = 64, TB = KT * 128, STAGE = TB * NPL * 2, NI = 2 * NPL;
-    constexpr int RPV = NSPLIT == 1 ? 2 : 4, RQK = NSPLIT == 1 ? 1 : 2;
+    // (LDS reads per fragment group: sw_reads above)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -715,13 +730,14 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     };
 
     PPFrags<T, NSPLIT> fr;
+    constexpr int NS = VTQ_SW_DIST + 1, DIST = VTQ_SW_DIST;
     auto issue_k = [&](auto gc, const uint32_t (&kaddr)[4]) __attribute__((always_inline)) {       // QK^T group g = kb * 4 + tt
-        constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3, off = kb * 4096;
+        constexpr int g = decltype(gc)::value, sl = g % NS, kb = g >> 2, tt = g & 3, off = kb * 4096;
         PP_DS_B128(fr.ka[sl], kaddr[tt], off);
         if constexpr (NSPLIT == 3) PP_DS_B128(fr.kl[sl], kaddr[tt], off + TB);
     };
     auto issue_v = [&](auto gc, const uint32_t (&vaddr)[2]) __attribute__((always_inline)) {       // PV group g = step * 2 + d
-        constexpr int g = decltype(gc)::value, sl = (g + 8) % 3, step = g >> 1, d = g & 1, off = (step >> 1) * 4096 + (step & 1) * 2048;
+        constexpr int g = decltype(gc)::value, sl = (g + 8) % NS, step = g >> 1, d = g & 1, off = (step >> 1) * 4096 + (step & 1) * 2048;
         PP_DS_TR(fr.va0[sl], vaddr[d], off);
         PP_DS_TR(fr.va1[sl], vaddr[d], off + 1024);
         if constexpr (NSPLIT == 3) {
@@ -730,6 +746,13 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         }
     };
 
+    auto issue_g = [&](auto Gc, const uint32_t (&kaddr)[4], const uint32_t (&vaddr)[2]) __attribute__((always_inline)) {   // group G of a tile
+        constexpr int G = decltype(Gc)::value;
+        if constexpr (G < 8) issue_k(std::integral_constant<int, G>{}, kaddr);
+        else if constexpr (G < 16) issue_v(std::integral_constant<int, G - 8>{}, vaddr);
+    };
+    auto ahead_of = [](int G, int end) constexpr { return sw_ahead<NSPLIT>(G, end); };
+
     // ---- pipeline prologue: S(0) = QK^T of tile 0 and its softmax, no overlap ---------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pp_barrier();
@@ -737,12 +760,12 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         uint32_t kaddr[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) kaddr[tt] = k_lane[tt];
-        issue_k(std::integral_constant<int, 0>{}, kaddr);
-        issue_k(std::integral_constant<int, 1>{}, kaddr);
+        const uint32_t vnone[2] = {0, 0};
+        static_for<0, DIST>([&](auto gc) __attribute__((always_inline)) { issue_g(gc, kaddr, vnone); });
         static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3;
-            if constexpr (g + 2 < 8) issue_k(std::integral_constant<int, g + 2>{}, kaddr);
-            constexpr int ahead = (g + 1 < 8 ? RQK : 0) + (g + 2 < 8 ? RQK : 0);
+            constexpr int g = decltype(gc)::value, sl = g % NS, kb = g >> 2, tt = g & 3;
+            if constexpr (g + DIST < 8) issue_g(std::integral_constant<int, g + DIST>{}, kaddr, vnone);
+            constexpr int ahead = ahead_of(g, 8);
             if constexpr (NSPLIT == 3) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.ka[sl]), "+v"(fr.kl[sl]) : "i"(ahead));
             else asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fr.ka[sl]) : "i"(ahead));
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -836,13 +859,11 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if (!active1 && !active2) {
         } else
         if constexpr (more) {
-            issue_k(std::integral_constant<int, 0>{}, kaddr);
-            issue_k(std::integral_constant<int, 1>{}, kaddr);
+            static_for<0, DIST>([&](auto gc) __attribute__((always_inline)) { issue_g(gc, kaddr, vaddr); });
             static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
-                constexpr int g = decltype(gc)::value, sl = g % 3, kb = g >> 2, tt = g & 3;
-                if constexpr (g + 2 < 8) issue_k(std::integral_constant<int, g + 2>{}, kaddr);
-                else issue_v(std::integral_constant<int, g + 2 - 8>{}, vaddr);
-                constexpr int ahead = (g + 1 < 8 ? RQK : RPV) + (g + 2 < 8 ? RQK : RPV);
+                constexpr int g = decltype(gc)::value, sl = g % NS, kb = g >> 2, tt = g & 3;
+                issue_g(std::integral_constant<int, g + DIST>{}, kaddr, vaddr);
+                constexpr int ahead = ahead_of(g, 16);
                 if constexpr (NSPLIT == 3) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.ka[sl]), "+v"(fr.kl[sl]) : "i"(ahead));
                 else asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fr.ka[sl]) : "i"(ahead));
                 __builtin_amdgcn_sched_barrier(0);
@@ -862,8 +883,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         } else {
             // last tile of the stream: no QK^T left; split without cover, first PV fragments
             static_for<0, 8>([&](auto gc) __attribute__((always_inline)) { split_half(gc); });
-            issue_v(std::integral_constant<int, 0>{}, vaddr);
-            issue_v(std::integral_constant<int, 1>{}, vaddr);
+            static_for<8, 8 + DIST>([&](auto gc) __attribute__((always_inline)) { issue_g(gc, kaddr, vaddr); });
         }
         VTQ_AT_SPAN(dg_p1);
         // output of the block that ended with the previous iteration's PV: phase 1 did not touch O; its stores are older than this
@@ -876,9 +896,9 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         // ---------------- phase 2: PV(tau) into O  ||  softmax of sB (tile tau + 1) -------------------------------------------
         bool sent = false, q_loaded = false;
         auto pv_group = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value, sl = (g + 8) % 3, step = g >> 1, d = g & 1;
-            if constexpr (g + 2 < 8) issue_v(std::integral_constant<int, g + 2>{}, vaddr);
-            constexpr int ahead = (g + 1 < 8 ? RPV : 0) + (g + 2 < 8 ? RPV : 0);
+            constexpr int g = decltype(gc)::value, sl = (g + 8) % NS, step = g >> 1, d = g & 1;
+            issue_g(std::integral_constant<int, g + 8 + DIST>{}, kaddr, vaddr);          // nothing beyond group 15
+            constexpr int ahead = ahead_of(g + 8, 16);
             if constexpr (NSPLIT == 3)
                 asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(fr.va0[sl]), "+v"(fr.va1[sl]), "+v"(fr.vl0[sl]), "+v"(fr.vl1[sl]) : "i"(ahead));
             else
