@@ -141,10 +141,20 @@ def test_full_size_properties(precision):
         # (3) identical ref and dist -> zero CLS difference -> every pair gets the same score, head(0)
         q_same = model((p[0], p[0]), (ps[0], ps[0]), (None, None))[0]
         assert torch.equal(q_same, q_same[:1].expand(B))
+        # (4) a patch set is a SET (get_iqa_patches draws the patches in random order, data/patch_sampling.py:529-611; nothing in the
+        #     forward depends on the order but the order of the softmax / PV sums): permuting the N patches of every image, with
+        #     their positions, moves the score by rounding only -- this crosses every key tile and query block of the attention kernels
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(7)).to(DEV)
+        q_perm = model(tuple(t[:, perm].contiguous() for t in p), tuple(t[:, perm].contiguous() for t in ps), (None, None))[0]
+        e_perm = gate_error(q_perm.cpu().numpy(), q.cpu().numpy())
+        print(f"\n[full-size {precision}] patch order: {e_perm:.2e}")
+        # 3-term attention: 2e-5 (fp16x3) .. 2e-4 (bf16x3); single-plane attention rounds P and the scores' operands to 11 / 8 bits,
+        # differently per order: the change is the mode's own error level (1.9e-2 fp16, 2.5e-1 bf16)
+        assert e_perm < TOL[precision] * (0.2 if precision.endswith(("x3", "x2")) else 1.2), e_perm
     zero = torch.zeros(1, 1, spec.hidden_size)
     q0 = O.head(O.to_torch(sd), spec, zero, zero)
     assert abs(float(q_same[0]) - float(q0[0])) < 1e-6 + 1e-5 * abs(float(q0[0]))
-    # (4) oracle on the host for a few pairs of the full-size batch (exact same inputs)
+    # (5) oracle on the host for a few pairs of the full-size batch (exact same inputs)
     cp, cps, _ = split_inputs(patches[sel], pos[sel], None)
     q_ref = O.vtamiq_forward(O.to_torch(sd), spec, cp, cps, (None, None))[0].numpy()
     e = rel_err(q[sel].cpu().numpy(), q_ref)
