@@ -69,6 +69,21 @@ __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x
     }
 }
 
+// Two scores at a time: the exponent's argument and the row sum as packed fp32 operations (v_pk_add_f32 / v_pk_fma_f32: two lanes'
+// worth of work per vector issue slot; the exponential itself has no packed form).  The row sum therefore runs as TWO partial sums
+// (even / odd accumulator registers), added at the end of a tile -- both kernels use this helper, so they stay bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NSPLIT>
+__device__ __forceinline__ void exp_pair(f32x16& v, int r, float m_new, float sc, float nm, f32x2& rs2) {      // registers r, r + 1 of v
+    f32x2 t = {v[r], v[r + 1]};
+    if constexpr (NSPLIT == 3) t = t - f32x2{m_new, m_new};
+    else t = t * f32x2{sc, sc} + f32x2{nm, nm};
+    f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    v[r] = pv[0];
+    v[r + 1] = pv[1];
+    rs2 += pv;
+}
+
 // 3-term formats: the softmax scale (1/sqrt(64) * log2 e) is folded into Q once per query block -- q c = (hi + lo) c in fp32, split
 // again -- so that scores arrive in log2 units and the exponent is exp2(s - m): one subtraction that is EXACT for the row maximum at
 // any magnitude.  (The one-FMA form exp2(s c - m c) subtracts the rounded product m c: fine at ordinary logits, inf at the 1e13
@@ -228,16 +243,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                                              // running max (3-term: log2 units; else raw)
         float nm = -m_new * sc;
-        float rs = 0.f;
+        f32x2 rs2 = {0.f, 0.f};
         if constexpr (NSPLIT == 3) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
-                    sacc[kb][r] = pv;
-                    rs += pv;
-                }
+                for (int r = 0; r < 16; r += 2) exp_pair<NSPLIT>(sacc[kb], r, m_new, sc, nm, rs2);
         } else {
             // single plane: exp2(s c - m c) as ONE FMA per score is exact enough only while |m c| is small: the FMA subtracts the ROUNDED
             // product m c, so the maximum's own exponent is the rounding error of m c (2^-24 |m c|) instead of 0 -- harmless at
@@ -253,12 +264,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, nm));
-                    sacc[kb][r] = pv;
-                    rs += pv;
-                }
+                for (int r = 0; r < 16; r += 2) exp_pair<NSPLIT>(sacc[kb], r, m_new, sc, nm, rs2);
         }
+        const float rs = rs2[0] + rs2[1];
         if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {        // some row's max moved: rescale (exact; usually skipped)
             const float alpha = __builtin_amdgcn_exp2f(NSPLIT == 3 ? m_run - m_new : (m_run - m_new) * sc);
             l_run *= alpha;
@@ -678,7 +686,8 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
                 }
         }
     };
-    float mx = 0.f, m_new = 0.f, nm = 0.f, rs = 0.f;
+    float mx = 0.f, m_new = 0.f, nm = 0.f;
+    f32x2 rs2 = {0.f, 0.f};
     auto max_part = [&](int half) __attribute__((always_inline)) {          // half 0 / 1: the eight v_max3 of sB[half]
         if (half == 0) mx = sB[0][0];
 #pragma unroll
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             mx = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
             m_new = fmaxf(m_run, mx);
             nm = NSPLIT == 3 ? -m_new : -m_new * sc;     // 3-term: log2 units already
-            rs = 0.f;
+            rs2 = f32x2{0.f, 0.f};
             if constexpr (NSPLIT != 3) {                 // huge logits (wave-uniform, rare): subtract first, see attention_kernel
                 if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
 #pragma unroll
@@ -706,16 +715,10 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             }
         }
     };
-    auto exp_part = [&](int i0, int i1) __attribute__((always_inline)) {    // scores i0 .. i1 - 1 of the 32
+    auto exp_part = [&](int i0, int i1) __attribute__((always_inline)) {    // scores i0 .. i1 - 1 of the 32 (even bounds: pairs)
 #pragma unroll
-        for (int i = i0; i < i1; ++i) {
-            float pv;
-            if constexpr (NSPLIT == 3) pv = __builtin_amdgcn_exp2f(sB[i >> 4][i & 15] - m_new);
-            else pv = __builtin_amdgcn_exp2f(fmaf(sB[i >> 4][i & 15], sc, nm));
-            sB[i >> 4][i & 15] = pv;
-            rs += pv;
-        }
-        asm volatile("" : "+v"(rs));            // the slice is computed in the group it is written in
+        for (int i = i0; i < i1; i += 2) exp_pair<NSPLIT>(sB[i >> 4], i & 15, m_new, sc, nm, rs2);
+        asm volatile("" : "+v"(rs2));           // the slice is computed in the group it is written in
 #pragma unroll
         for (int i = i0; i < i1; ++i) asm volatile("" : "+v"(sB[i >> 4][i & 15]));
     };
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             l_run *= alpha;
         }
         m_run = m_new;
-        l_run += rs;
+        l_run += rs2[0] + rs2[1];
     };
 
     PPFrags<T, NSPLIT> fr;
@@ -918,10 +921,10 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
                 else if constexpr (g == 1) max_part(1);
                 else if constexpr (g == 2) exp_part(0, 6);
                 else if constexpr (g == 3) exp_part(6, 12);
-                else if constexpr (g == 4) exp_part(12, 17);
-                else if constexpr (g == 5) exp_part(17, 22);
-                else if constexpr (g == 6) exp_part(22, 27);
-                else exp_part(27, 32);
+                else if constexpr (g == 4) exp_part(12, 18);
+                else if constexpr (g == 5) exp_part(18, 22);
+                else if constexpr (g == 6) exp_part(22, 28);
+                else exp_part(28, 32);
                 if constexpr (NSPLIT == 3) { SW_MFMA_VALU(5); SW_MFMA_VALU(5); SW_MFMA_VALU(5); }
                 else { SW_MFMA_VALU(6); }
             }
