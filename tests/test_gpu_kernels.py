@@ -193,6 +193,32 @@ def test_attention_kernels_agree_bitwise(fmt, nseq, S, H):
         assert torch.equal(outs[-2][:, : nseq * S], outs[-1][:, : nseq * S])
 
 
+@pytest.mark.parametrize("fmt", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_huge_logits(fmt, variant):
+    """Scores of 1e12 .. 1e13 (Q, K of a 1e7-gain LayerNorm: the fp32 reference's softmax is finite there, train.py:602-607).  The
+    exponent must subtract the row maximum exactly: exp2(s c - m c) as one FMA subtracts the ROUNDED product m c and returned inf
+    (round 3).  3-term formats take the log2-domain path (scale folded into Q), single-plane formats the magnitude guard."""
+    lib = _lib.load()
+    nseq, S, H = 3, 200, 768
+    rows = nseq * S + 128
+    qkv = _randn(rows, 3 * H, seed=21, scale=1.0)
+    qkv[:, : 2 * H] *= 2.0e6                                   # Q and K; V stays O(1)
+    P = to_planes(qkv, fmt, "a")
+    out = torch.zeros((P.shape[0], rows, H), dtype=elt_dtype(fmt), device=DEV)
+    lib.vtq_debug_attention_variant(variant)
+    try:
+        _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, out.data_ptr(), rows * H, nseq, S, S, H, num_code(fmt), stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.vtq_debug_attention_variant(-1)
+    got = planes_value(out)[: nseq * S].view(nseq, S, H)
+    assert bool(torch.isfinite(got).all())
+    ref = _attention_ref(planes_value(P)[: nseq * S], nseq, S, S, H)      # fp64 softmax of the same (rounded) operands: one-hot rows
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < {"bf16x3": 2e-4, "bf16": 1.5e-2}[fmt], err
+
+
 def _skinny(x, W, bias, fmt, epi=0, post=None, gamma=None, res=None, aux=None, nsplit=0, want_y=True, ycols=None, planes_out=False,
             pcol0=0, next_slope=None, Kp=None):
     """Drive vtq_k_skinny_linear: x [R, K] fp32, W [N, K] fp32 -> (y fp32 or None, planes value fp64 or None)."""
