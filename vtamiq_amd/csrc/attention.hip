@@ -425,6 +425,9 @@ struct PPFrags {                      // DIST + 1 rolling fragment buffers: grou
 #ifndef VTQ_SW_NOSTORE
 #define VTQ_SW_NOSTORE 0
 #endif
+#ifndef VTQ_SW_PAIRED
+#define VTQ_SW_PAIRED 1
+#endif
 #ifndef VTQ_SW_NOQ
 #define VTQ_SW_NOQ 0
 #endif
@@ -505,9 +508,23 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     const int nqb = (S_pad + 255) / 256, nh = H / 64;
     const int nt = (S + KT - 1) / KT;
     const int ld = 3 * H;
-    const int b0 = blockIdx.x * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    // Blocks of this workgroup: b0, b0 + bstep, ... < b1.  With two query blocks per (sequence, head) and a grid that divides evenly,
+    // workgroups w and w + 8 (same XCD under the round-robin dispatch) take the two query blocks of the same pairs at the same time, so
+    // that the second reader of every K / V tile finds it in that XCD's L2; otherwise contiguous runs of blocks.
+    int b0, b1, bstep;
+    if (VTQ_SW_PAIRED && nqb == 2 && (gridDim.x & 15) == 0 && (int)gridDim.x * per == nblk) {
+        const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+        const int g = x * ((int)gridDim.x >> 4) + (sl >> 1);
+        b0 = 2 * g * per + (sl & 1);
+        bstep = 2;
+        b1 = b0 + 2 * per;
+    } else {
+        b0 = blockIdx.x * per;
+        b1 = (b0 + per < nblk) ? b0 + per : nblk;
+        bstep = 1;
+    }
     if (b0 >= b1) return;
-    const int NT = (b1 - b0) * nt;
+    const int NT = ((b1 - b0 + bstep - 1) / bstep) * nt;
     const float sc = 0.125f * 1.4426950408889634f;
 #ifdef VTQ_ATTN_DIAG
     unsigned long long dg_k0, dg_r0, dg_t, dg_p1 = 0, dg_p2 = 0, dg_bar = 0, dg_pro = 0, dg_rest = 0;
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         ++itau;
         if (++it == nt) {
             it = 0;
-            if (++ib < b1) ibase = block_base(ib, iqb);
+            if ((ib += bstep) < b1) ibase = block_base(ib, iqb);
         }
         return true;
     };
@@ -788,8 +805,8 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         finish_softmax();
 #pragma unroll
         for (int d = 0; d < 2; ++d) sA[d] = sB[d];
-        if (nt == 1 && b0 + 1 < b1) {                          // single-tile blocks: the next QK^T already belongs to the next block
-            load_q_async(b0 + 1, qf);
+        if (nt == 1 && b0 + bstep < b1) {                      // single-tile blocks: the next QK^T already belongs to the next block
+            load_q_async(b0 + bstep, qf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pin_q(qf);
             if constexpr (NSPLIT == 3) { if (!q_log2) prescale_q<T>(qf, sc); }
@@ -936,7 +953,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         // Q of the block after the one tile tau + 1 belongs to: its registers are free once the QK^T of that block's last tile has run
         // (phase 1 above); loaded in place, hidden from hipcc's vmcnt bookkeeping, complete behind the counted wait at the end
         if constexpr (more) {
-            const int bq = (tb_next == 0 ? cb + 1 : cb) + 1;
+            const int bq = (tb_next == 0 ? cb + bstep : cb) + bstep;
             if (tb_next == nt - 1 && bq < b1 && !VTQ_SW_NOQ) { load_q_async(bq, qf); q_loaded = true; }
         }
         sent = issue_tile();                                    // tile tau + 3: younger than the Q loads and stores, so vmcnt(NI) below covers them
@@ -946,7 +963,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if (seam) {
             wr_pending = true; wr_b = cb; wr_qb = cqb;
             ct = 0;
-            if (++cb < b1) block_base(cb, cqb);
+            if ((cb += bstep) < b1) block_base(cb, cqb);
         } else {
             ++ct;
         }
