@@ -88,7 +88,8 @@ def compute_correlations(a: torch.Tensor, b: torch.Tensor, normalize: bool = Tru
     except OverflowError:
         pass
     xm, ym = aa - aa.mean(), fitted - fitted.mean()
-    pearson = float(np.clip(np.dot(xm / np.linalg.norm(xm), ym / np.linalg.norm(ym)), -1.0, 1.0))
+    with np.errstate(divide="ignore", invalid="ignore"):              # a constant input has no correlation: nan, as scipy.stats.pearsonr
+        pearson = float(np.clip(np.dot(xm / np.linalg.norm(xm), ym / np.linalg.norm(ym)), -1.0, 1.0))
     rmse = float(np.sqrt(np.mean((aa - fitted) ** 2)))
     return {SROCC_FIELD: spearman, KROCC_FIELD: kendall, PLCC_FIELD: pearson, RMSE_FIELD: rmse,
             PLCC_NOFIT_FIELD: pearson_nofit, RMSE_NOFIT_FIELD: rmse_nofit}
