@@ -39,6 +39,26 @@ __global__ __launch_bounds__(512) void skinny_linear_kernel(SkinnyArgs p) {   //
     f32x4 acc[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Epilogue operands of the finishing waves (wave w < RB finishes row block w), requested here so that their latency passes under the
+    // product's instead of after it: a stage is a chain of exposed latencies and little else.
+    const int e_row = r0 + wave * 16 + fr, e_n = n0 + 4 * fq;
+    const bool e_live = wave < RB && e_row < p.R && e_n < p.N;
+    float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_aux[4] = {0.f, 0.f, 0.f, 0.f}, e_gam[4] = {1.f, 1.f, 1.f, 1.f};
+    float post = 0.f, nxt = 1.f;
+    if (e_live) {
+        post = p.post_slope ? *p.post_slope : 0.f;
+        nxt = p.next_slope ? *p.next_slope : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = e_n + e;
+            if (c < p.N) {
+                e_bias[e] = p.bias[c];
+                if (p.epi == SK_RESID || p.epi == SK_GATE) e_res[e] = p.res[(int64_t)e_row * p.ldr + c];
+                if (p.epi == SK_GATE) e_aux[e] = p.aux[(int64_t)e_row * p.ldr + c];
+                if (p.epi == SK_RESID && p.gamma) e_gam[e] = p.gamma[c];
+            }
+        }
+    }
     const int nks = p.K >> 5;
     for (int base = wave; base < nks; base += NW * UN) {
         tx8 w[UN][WPL], x[UN][RB][APL];
@@ -79,22 +99,20 @@ __global__ __launch_bounds__(512) void skinny_linear_kernel(SkinnyArgs p) {   //
         const f32x4 o = *(const f32x4*)red[w][rb][lane];
         v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
     }
-    const int row = r0 + rb * 16 + fr;
-    const int n = n0 + 4 * fq;
-    if (row >= p.R || n >= p.N) return;
+    const int row = e_row;
+    const int n = e_n;
+    if (!e_live) return;
     float o[4];
-    const float post = p.post_slope ? *p.post_slope : 0.f;
-    const float nxt = p.next_slope ? *p.next_slope : 1.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = n + e;
-        float val = v[e] + ((c < p.N) ? p.bias[c] : 0.f);
+        float val = v[e] + e_bias[e];
         if (c < p.N) {
             switch (p.epi) {
                 case SK_GELU: val = gelu_erf(val); break;
                 case SK_PRELU: val = prelu1(val, post); break;
-                case SK_RESID: val = p.res[(int64_t)row * p.ldr + c] + (p.gamma ? p.gamma[c] : 1.0f) * val; break;
-                case SK_GATE: val = p.res[(int64_t)row * p.ldr + c] + p.aux[(int64_t)row * p.ldr + c] * (1.0f / (1.0f + __expf(-val))); break;
+                case SK_RESID: val = e_res[e] + e_gam[e] * val; break;
+                case SK_GATE: val = e_res[e] + e_aux[e] * (1.0f / (1.0f + __expf(-val))); break;
                 case SK_CONVCAT: if (c >= p.nsplit) val = fmaxf(val, 0.f); break;
                 default: break;
             }
@@ -154,8 +172,15 @@ __global__ __launch_bounds__(256) void rows_to_planes_kernel(const float* __rest
 
 hipError_t launch_skinny(const SkinnyArgs& a, Num num, hipStream_t s) {
     if (a.R < 1 || a.N < 1 || a.K < 32 || a.K % 32 || a.ldx % 8 || (a.ya && (a.pcol0 % 4 || a.ldya % 4)) || !num_valid(num)) return hipErrorInvalidValue;
-    const int rb = a.R <= 16 ? 1 : (a.R <= 32 ? 2 : 4);
-    const dim3 g((a.N + 15) / 16, (a.R + 16 * rb - 1) / (16 * rb)), blk(512);
+    // Rows per workgroup: every workgroup pulls its rows' activations through its CU's L1 (64 B / clk), which is what a stage's time is made
+    // of beyond the exposed latency, so split the rows over workgroups (16 each) while the grid still fits the 256 CUs in one round, and
+    // take 32 / 64 rows per workgroup for the wide stages (the tail's fc1).  The result does not depend on the choice: a row's sums are
+    // formed in the same order.
+    const int nb = (a.N + 15) / 16;
+    int rb = 4;
+    for (int t = 1; t <= 4; t *= 2)
+        if (a.R <= 16 * t || nb * ((a.R + 16 * t - 1) / (16 * t)) <= 256) { rb = t; break; }
+    const dim3 g(nb, (a.R + 16 * rb - 1) / (16 * rb)), blk(512);
 #define VTQ_SK(TT, TM)                                                                              \
     do {                                                                                            \
         if (rb == 1) hipLaunchKernelGGL((skinny_linear_kernel<TT, TM, 1>), g, blk, 0, s, a);        \
