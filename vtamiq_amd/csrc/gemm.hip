@@ -320,6 +320,25 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
                 float4 x = xv[ch & 1][ps];
                 x.x += dv[ps][0]; x.y += dv[ps][1]; x.z += dv[ps][2]; x.w += dv[ps][3];
                 *(float4*)(xg + (int64_t)grow_of(ch, ps) * p.N) = x;
+#ifdef VTQ_RESID_PLANES
+                // Pricing build (tools/ln_fold_price.py): what the producer side of a LayerNorm fold would add to this epilogue -- the new
+                // residual row also as the consumer's hi / lo operand planes, and the (mean, M2) of its 256 columns for a Chan combination.
+                if (p.out) {
+                    typedef typename Vec<T>::x4 tx4;
+                    const int64_t gr = m0 + grow_of(ch, ps);
+                    T* pg = (T*)p.out + gr * p.ldo + n0 + c16 * 4;
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+                    tx4 h, l;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { T a, b; split2<T>(xs[k], a, b); h[k] = a; l[k] = b; }
+                    *(tx4*)pg = h;
+                    *(tx4*)(pg + p.o_plane) = l;
+                    const float mt = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+                    const float d0 = x.x - mt, d1 = x.y - mt, d2 = x.z - mt, d3 = x.w - mt;
+                    const float m2 = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                    if (c16 == 0 && p.row_stats) *(float2*)(p.row_stats + (gr * (p.N >> 8) + (n0 >> 8)) * 2) = float2{mt, m2};
+                }
+#endif
             }
         };
         load_x(0);
@@ -944,6 +963,15 @@ template <typename T, int TERMS, int EPI> hipError_t launch_t(GemmArgs a, hipStr
     a.sched = ds.dev;
     a.diag = g_diag_buf;
     a.shadow = g_diag_shadow;
+#ifdef VTQ_RESID_PLANES
+    {   // pricing build: a statistics buffer nothing reads (one per process, sized for the largest M x N / 256 asked for so far)
+        static float* stats = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)a.M * (a.N / 256) * 2 * sizeof(float);
+        if (need > cap) { if (stats) (void)hipFree(stats); if (hipMalloc((void**)&stats, need) != hipSuccess) return hipErrorOutOfMemory; cap = need; }
+        a.row_stats = stats;
+    }
+#endif
     hipLaunchKernelGGL((gemm_pp2_kernel<T, TERMS, EPI>), dim3(ds.nwg), dim3(512), LDS, s, a);
     return hipGetLastError();
 }

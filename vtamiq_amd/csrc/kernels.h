@@ -68,6 +68,7 @@ struct GemmArgs {
     // diagnostic builds (-DVTQ_GEMM_DIAG, tools/build_abl.sh) only; set by launch_gemm from gemm_set_diag, never read otherwise:
     unsigned long long* diag;                     //   per workgroup 8 words: K-loop and whole-kernel s_memtime / s_memrealtime sums
     int shadow;                                   //   dummy v_fma_f32 issued in every load phase (x8): the price of VALU work beside the partner's MFMAs
+    float* row_stats;                             //   -DVTQ_RESID_PLANES pricing build only: per row and column tile (mean, M2) of the new residual row
 };
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
