@@ -134,6 +134,7 @@ struct vtq_engine {
     int64_t tl_plane = 0, th_plane = 0;
     float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr;   // CLS-only last layer (fp32 rows)
     bool cls_prune = true;
+    int32_t* err_host = nullptr;         // pinned landing word of vtq_input_errors (a pageable destination goes through the runtime's staging path)
     int* err_flag = nullptr;             // device word (vtq_input_errors): bit 0 = a position outside [0, 1) was clamped, bit 1 = non-finite CLS difference
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
@@ -729,6 +730,11 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     }
     e->allocs.push_back(e->err_flag);
     e->amax_slot = (float*)(e->err_flag + 2);           // same 16-byte allocation
+    if (hipHostMalloc((void**)&e->err_host, 64, hipHostMallocDefault) != hipSuccess) {
+        e->err_host = nullptr;
+        vtq_destroy(e);
+        return fail("vtq_create: pinned host allocation failed");
+    }
     if (build(e)) { vtq_destroy(e); return 1; }
     *out = e;
     return 0;
@@ -738,6 +744,7 @@ void vtq_destroy(vtq_handle e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
+    if (e->err_host) (void)hipHostFree(e->err_host);
     for (void* p : e->ws_allocs) (void)hipFree(p);
     for (auto& ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -988,11 +995,10 @@ int vtq_forward_pairwise(vtq_handle e, const float* const* patches, const float*
 int vtq_input_errors(vtq_handle e, int32_t* flags, void* stream) {
     if (!e || !flags) return fail("vtq_input_errors: null argument");
     hipStream_t s = (hipStream_t)stream;
-    int32_t h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, e->err_flag, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemsetAsync(e->err_flag, 0, 4, s));
+    HIP_TRY(hipMemcpyAsync(e->err_host, e->err_flag, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *flags = h;
+    *flags = *e->err_host;
+    HIP_TRY(hipMemsetAsync(e->err_flag, 0, 4, s));      // after the wait: it runs under the caller's next host-side work, ahead of the next forward in stream order
     return 0;
 }
 

@@ -256,7 +256,10 @@ class VTAMIQ(nn.Module):
         if ps is None:                               # the parameter OBJECTS are fixed after construction (.to() / load_state_dict
             ps = list(self.parameters())             # write into them): walk the module tree once, not on every forward
             self.__dict__["_param_cache"] = ps
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        # version counters only grow, so their sum changes iff any parameter was written in place (load_state_dict, optimizer-style
+        # ops); storage replacement goes through _apply (.to() / .cuda()), which resets the packed state itself.  One attribute read per
+        # parameter: this runs on every forward, and with precision="auto" the device waits for the host between forwards.
+        return sum(p._version for p in ps)
 
     def _release_engine(self):
         eng = self.__dict__.get("_engine")
