@@ -219,6 +219,36 @@ def test_attention_huge_logits(fmt, variant):
     assert err < {"bf16x3": 2e-4, "bf16": 1.5e-2}[fmt], err
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "bf16"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_rows_do_not_depend_on_the_next_sequence(fmt, variant):
+    """Packed sequences (pitch = S): the lanes of a ragged last query group hold the NEXT sequence's rows.  The single-plane formats'
+    magnitude guard (|m c| > 64: subtract the maximum first) is a per-row decision -- a wave-wide one let a huge neighbour switch the
+    valid rows of that group to the other rounding path (found by tools/attn_stress.py in round 3: the two kernels, which fill those
+    lanes differently, differed in single elements).  Sequence 0 alone and sequence 0 followed by a sequence with huge logits must
+    give the same bits for sequence 0."""
+    lib = _lib.load()
+    S, H = 300, 768                                            # 300 = 9 x 32 + 12: rows 288 .. 299 share a wave with 20 foreign rows
+    rows = 2 * S + 128
+    qkv = _randn(rows, 3 * H, seed=33, scale=2.0)              # |m c| of a few tens: below the guard for most rows, around it for some
+    qkv[S:2 * S, : 2 * H] *= 40.0                              # the neighbour: far beyond it
+    outs = []
+    for second in (False, True):
+        x = qkv.clone()
+        if not second:
+            x[S:] = 0.0
+        P = to_planes(x, fmt, "a")
+        out = torch.zeros((P.shape[0], rows, H), dtype=elt_dtype(fmt), device=DEV)
+        lib.vtq_debug_attention_variant(variant)
+        try:
+            _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, out.data_ptr(), rows * H, 2 if second else 1, S, S, H, num_code(fmt), stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.vtq_debug_attention_variant(-1)
+        outs.append(out[:, :S].view(torch.int16).clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def _skinny(x, W, bias, fmt, epi=0, post=None, gamma=None, res=None, aux=None, nsplit=0, want_y=True, ycols=None, planes_out=False,
             pcol0=0, next_slope=None, Kp=None):
     """Drive vtq_k_skinny_linear: x [R, K] fp32, W [N, K] fp32 -> (y fp32 or None, planes value fp64 or None)."""

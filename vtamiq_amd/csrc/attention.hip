@@ -253,13 +253,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             // single plane: exp2(s c - m c) as ONE FMA per score is exact enough only while |m c| is small: the FMA subtracts the ROUNDED
             // product m c, so the maximum's own exponent is the rounding error of m c (2^-24 |m c|) instead of 0 -- harmless at
             // |m c| <= 64 (3e-6), inf at the logits of a 1e7-gain model (the fp32 reference returns finite scores there).  Beyond 64
-            // (wave-uniform, rare): subtract the maximum first, then the same FMA with a zero addend.
-            if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
+            // (rare; the branch is wave-uniform, the decision per query row, so a row's bits never depend on its wave's other rows):
+            // subtract the maximum first, then the same FMA with a zero addend.
+            const bool big = fabsf(nm) > 64.f;
+            if (__builtin_amdgcn_ballot_w64(big)) {
+                const float sub = big ? m_new : 0.f;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= m_new;
-                nm = 0.f;
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= sub;
+                nm = big ? 0.f : nm;
             }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
@@ -721,13 +724,15 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             m_new = fmaxf(m_run, mx);
             nm = NSPLIT == 3 ? -m_new : -m_new * sc;     // 3-term: log2 units already
             rs2 = f32x2{0.f, 0.f};
-            if constexpr (NSPLIT != 3) {                 // huge logits (wave-uniform, rare): subtract first, see attention_kernel
-                if (__builtin_amdgcn_ballot_w64(fabsf(nm) > 64.f)) {
+            if constexpr (NSPLIT != 3) {                 // huge logits (rare; decided per query row): subtract first, see attention_kernel
+                const bool big = fabsf(nm) > 64.f;
+                if (__builtin_amdgcn_ballot_w64(big)) {
+                    const float sub = big ? m_new : 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sB[kb][r] -= m_new;
-                    nm = 0.f;
+                        for (int r = 0; r < 16; ++r) sB[kb][r] -= sub;
+                    nm = big ? 0.f : nm;
                 }
             }
         }
