@@ -146,8 +146,8 @@ def test_attention_kernel_rule():
 
 def test_gemm_tile_schedule_covers_every_tile_once():
     """The host-built persistent schedule of the GEMM (gemm.hip build_schedule): 256 per-workgroup lists; every 256x256 tile
-    appears exactly once, either whole or as its top AND bottom half; half tiles only close a list; lists are balanced; pure
-    host code, callable without a GPU."""
+    appears exactly once, either whole or as its top AND bottom half; half tiles close a list, or -- one of them, on the odd XCDs
+    (the epilogue stagger) -- open it; lists are balanced; pure host code, callable without a GPU."""
     import ctypes as C
     import numpy as np
     from vtamiq_amd import _lib
@@ -170,13 +170,20 @@ def test_gemm_tile_schedule_covers_every_tile_once():
         assert ((whole == 1) & (top == 0) & (bot == 0) | (whole == 0) & (top == 1) & (bot == 1)).all(), (M, N)
         assert len(ent) == nt + int((kind == 1).sum())
         loads = []
+        staggered = 0
         for b in range(nwg):
             k = out[offs[b]:offs[b + 1]] & 3
             if len(k):
-                first_half = np.argmax(k != 0) if (k != 0).any() else len(k)
-                assert (k[first_half:] != 0).all(), "a whole tile after a half tile"
+                body = k[1:] if (k[0] != 0 and (b % 8) % 2 == 1 and len(k) >= 2 and k[1] == 0) else k     # staggered list: its half tile first
+                if body is not k:
+                    staggered += 1
+                    assert (body == 0).all(), "a staggered list holds one half tile"
+                first_half = np.argmax(body != 0) if (body != 0).any() else len(body)
+                assert (body[first_half:] != 0).all(), "a whole tile after a half tile"
             loads.append(float((k == 0).sum() + 0.57 * (k != 0).sum()))
         assert max(loads) - min(loads) <= 1.0 + 1e-9, (M, N, min(loads), max(loads))
+        if (M, N, K) == (32768, 768, 768):
+            assert staggered > 0                  # (whole, half) lists on the odd XCDs run the half first
         # workgroup b runs on XCD b % 8: the XCD owns a contiguous run of the row-major tile order
         for x in range(8):
             mine = np.concatenate([out[offs[b]:offs[b + 1]] >> 2 for b in range(x, nwg, 8)])

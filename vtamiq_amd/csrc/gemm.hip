@@ -789,7 +789,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 //     workgroups take consecutive entries, so at any time they work on 32/cg row panels x cg column tiles, and the cg W tiles
 //     (cg * 256 * K * planes * 2 B, sized to ~2.5 MiB) stay L2-resident while the panels stream past.
 //   * The run ENDS with 128x256 half tiles, so the last round is filled in half-tile granules; how many tiles to split is
-//     chosen by simulating the greedy list assignment (half tile = 0.57 of a tile, measured).
+//     chosen by simulating the greedy list assignment (half tile = 0.57 of a tile, measured).  On the odd XCDs a workgroup whose
+//     list closes with ONE half tile runs it first instead (stagger, below).
 //   * Entries are dealt to the XCD's workgroups in order, each to the least loaded one (what a dynamic queue would do with
 //     these costs).  Output never depends on the schedule: every element is accumulated over K in the same order in both
 //     tile forms, so results are bitwise independent of batch size and placement.
@@ -853,6 +854,17 @@ std::vector<int> build_schedule(int ntm, int ntn, int cg) {
             lists[x + kXcds * best].push_back(e);
         }
     }
+    // Stagger: on the odd XCDs a workgroup runs its closing half tile FIRST.  All tiles of a launch take the same time, so otherwise every
+    // workgroup of the chip reaches its epilogue -- a burst of stores and, in the residual form, loads -- at the same moments; with the
+    // half tile in front, the odd XCDs' epilogues fall about half a tile after the even ones'.  Whole XCDs, not every second CU of one:
+    // the column tiles of a row panel that share their A panel through the XCD's L2 stay in step (per-CU staggering cost fc2 3.5 %).
+    // Same work, same results (profiles/r03_gemm_stagger.txt: out-proj -6 %, QKV -3 %, fc2 and fc1 unchanged; VTQ_GEMM_STAGGER=0: off).
+    static const bool stagger = [] { const char* v = getenv("VTQ_GEMM_STAGGER"); return !(v && v[0] == '0'); }();
+    if (stagger)
+        for (int b = 0; b < kNumCus; ++b) {
+            std::vector<int>& l = lists[b];
+            if (((b % kXcds) & 1) && l.size() >= 2 && (l.back() & 3) && !(l[l.size() - 2] & 3)) { const int h = l.back(); l.pop_back(); l.insert(l.begin(), h); }
+        }
     std::vector<int> out(kNumCus + 1);
     int off = kNumCus + 1;
     for (int b = 0; b < kNumCus; ++b) { out[b] = off; off += (int)lists[b].size(); }
