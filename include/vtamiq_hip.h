@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 4
+#define VTQ_ABI_VERSION 5
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -65,8 +65,15 @@ typedef struct vtq_config {
     int32_t ca_hidden;         /* hidden_size / ca_reduction (channel_attention.py:75)                */
     int32_t precision;         /* VTQ_PREC_*                                                          */
     int32_t num_adapters;      /* Adapter pairs per layer (transformer.py:260-269); pair 0 is applied   */
-    int32_t reserved[4];
+    int32_t options;           /* VTQ_OPT_* bit mask (tests and measurement; 0 = the product path)      */
+    int32_t reserved[3];
 } vtq_config;
+
+/* vtq_config.options.  The library reads NO environment variable: what rounds 1-3 steered through VTQ_NO_CLS_PRUNE /
+ * VTQ_FP8_STATIC_SCALES is an explicit field of the configuration the caller hands over. */
+#define VTQ_OPT_FULL_LAST_LAYER   1   /* run the last encoder layer on every token row instead of on the CLS rows only (same result) */
+#define VTQ_OPT_FP8_STATIC_SCALES 2   /* VTQ_PREC_FP8: keep the static default activation scales, never calibrate                    */
+#define VTQ_OPT_SEPARATE_LAYERNORM 4  /* LayerNorm as its own launch in front of QKV / fc1 instead of inside the residual GEMMs     */
 
 typedef struct vtq_tensor_desc {
     const char*  name;         /* HOST string: the reference's state_dict key          */
@@ -123,8 +130,9 @@ int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
  * layer l: [1 + 4l] LayerNorm-1 output, [2 + 4l] attention context, [3 + 4l] LayerNorm-2 output, [4 + 4l] GELU output.
  * An engine starts with static defaults (256, 8, 16, 8, 4) and CALIBRATES on the batch of its first vtq_forward: every producing
  * kernel reports max |value|, the largest power of two mapping it to <= 224 becomes the scale, the producer is run again with
- * it (one stream synchronisation per point, that forward only; its scores are computed with the final scales).  Environment
- * VTQ_FP8_STATIC_SCALES=1 keeps the defaults.  vtq_fp8_calibrate repeats the calibration on a batch of the caller's choice
+ * it (one stream synchronisation per point, that forward only; its scores are computed with the final scales).  vtq_config.options
+ * & VTQ_OPT_FP8_STATIC_SCALES keeps the defaults.  vtq_load_weights marks the engine uncalibrated again (scales fitted to other
+ * weights would clamp) unless the current scales were installed through vtq_fp8_set_scales.  vtq_fp8_calibrate repeats the calibration on a batch of the caller's choice
  * (arguments as vtq_forward); get / set expose the 1 + 4 * num_layers values (get returns the count, -1 for a non-fp8 engine;
  * set requires positive powers of two and marks the engine calibrated). */
 int  vtq_fp8_calibrate(vtq_handle h, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
@@ -150,7 +158,7 @@ int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t
 int  vtq_debug_gemm_diag(void* buf, int32_t shadow);
 /* Which of the two fused-attention kernels vtq_k_attention and the engine launch (process-wide; tests and measurement):
  * 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel, -1 = the library's rule (the pipelined kernel for the 3-term
- * formats when its 256-row blocks fill the chip; environment VTQ_ATTN_VARIANT overrides the rule).  Both compute the same arithmetic
+ * formats when its 256-row blocks fill the chip).  Both compute the same arithmetic
  * in the same order per query row: outputs are bit-identical. */
 int  vtq_debug_attention_variant(int32_t variant);
 /* Host-only: which kernel the library's rule gives nseq sequences of pitch S_pad, hidden size H, operand format num (VTQ_NUM_*) on a

@@ -332,6 +332,42 @@ def run_validation_metrics():
     np.savez(os.path.join(HERE, "validation_metrics.npz"), **out)
 
 
+def run_ladder_case(name, vtamiq_kwargs, images, N, wseed, iseed, stress_qk, chunk=8):
+    """SCORES ONLY, at the BASELINE patch count: the reference in fp32 and in float64 on stress_state weights over a distortion
+    ladder of images * 8 pairs (synth.make_ladder_inputs) -- the trained-like parity tail pinned by the reference itself at
+    N = 500.  Run in chunks of `chunk` pairs (the reference materialises every attention matrix)."""
+    kw = json.loads(json.dumps(vtamiq_kwargs))
+    spec = make_spec(**json.loads(json.dumps(kw)))
+    patches, pos, scales = synth.make_ladder_inputs(spec, images, N, iseed)
+    assert scales is None
+    B = patches.shape[0]
+    sdnp = seeded_state(spec, wseed, stress_qk)
+    out = dict(kwargs=json.dumps(vtamiq_kwargs), images=images, B=B, N=N, wseed=wseed, iseed=iseed, stress_qk=np.float64(stress_qk))
+    for tag, dt in (("q", torch.float32), ("q64", torch.float64)):
+        model = build_reference(kw).to(dt)
+        model.load_state_dict({k: torch.from_numpy(v).to(dt) for k, v in sdnp.items()}, strict=True)
+        qs = []
+        with torch.no_grad():
+            for i in range(0, B, chunk):
+                tp, tq = torch.from_numpy(patches[i:i + chunk]).to(dt), torch.from_numpy(pos[i:i + chunk]).to(dt)
+                q, aux = model((tp[:, 0].clone(), tp[:, 1].clone()), (tq[:, 0].clone(), tq[:, 1].clone()), (None, None))
+                assert aux is None
+                qs.append(q)
+                print(f"  {name} {tag}: {i + chunk}/{B}", flush=True)
+        out[tag] = torch.cat(qs).numpy().astype(np.float32 if dt == torch.float32 else np.float64)
+        del model
+    out["fp_patches"] = np.float64(patches.astype(np.float64).sum())
+    out["fp_pos"] = np.float64(pos.astype(np.float64).sum())
+    out["fp_weights"] = np.float64(sum(float(v.astype(np.float64).sum()) for v in sdnp.values()))
+    np.savez(os.path.join(HERE, f"{name}.npz"), **out)
+    d = np.abs(out["q"].astype(np.float64) - out["q64"]) / np.abs(out["q64"])
+    print(f"{name}: {B} scores, rms {np.sqrt(np.mean(out['q64'] ** 2)):.4f}; reference fp32 vs its own fp64: max {d.max():.2e}, p95 {np.percentile(d, 95):.2e}")
+
+
+def run_ladder():
+    run_ladder_case("stress5_b64_n500", dict(vit_config=dict(variant="ViT-B16")), images=8, N=500, wseed=32, iseed=777, stress_qk=5.0)
+
+
 def run_stress():
     """The reference itself on weights with trained-ViT-like statistics (tests.helpers.stress_state: peaked softmax, outlier
     channels) -- the flat random init of the other cases exercises none of that (transformer.py:153-172)."""
@@ -354,6 +390,9 @@ def main():
         run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
         run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--ladder":         # only the 64-pair N = 500 trained-like case (added in round 4; ~10 min)
+        run_ladder()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--stress":         # only the trained-like-statistics cases (added in round 3)
         run_stress()
         return
@@ -375,6 +414,7 @@ def main():
     run_case("adapters_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, num_adapters=2, use_layer_scale=True, num_extra_tokens=1)),
              B=2, N=40, wseed=22, iseed=19)
     run_stress()
+    run_ladder()
     run_ops()
     run_npz()
     run_plumbing()

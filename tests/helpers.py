@@ -32,6 +32,24 @@ def load_case(name):
     return g, kw, spec, sd, (patches, pos, scales)
 
 
+LADDER_CASES = ["stress5_b64_n500"]       # 64 pairs at the BASELINE patch count on trained-like weights: scores only (fp32 + float64)
+
+
+def load_ladder_case(name):
+    """-> (golden npz dict, kwargs, spec, numpy state dict, (patches, pos, None)) of a make_golden.run_ladder_case fixture."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    kw = json.loads(str(g["kwargs"]))
+    kw.setdefault("vit_config", {})["pretrained"] = False
+    spec = make_spec(**json.loads(json.dumps(kw)))
+    sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"]))
+    patches, pos, scales = synth.make_ladder_inputs(spec, int(g["images"]), int(g["N"]), int(g["iseed"]))
+    assert patches.shape[0] == int(g["B"])
+    assert abs(float(patches.astype(np.float64).sum()) - float(g["fp_patches"])) < 1e-6
+    assert abs(float(pos.astype(np.float64).sum()) - float(g["fp_pos"])) < 1e-6
+    assert abs(sum(float(v.astype(np.float64).sum()) for v in sd.values()) - float(g["fp_weights"])) < 1e-6
+    return g, kw, spec, sd, (patches, pos, scales)
+
+
 def split_inputs(patches, pos, scales, device="cpu", dtype=torch.float32):
     """Collated [B,2,...] numpy -> the ((ref,dist),(pos_ref,pos_dist),(sc_ref,sc_dist)) call tuple (train.py:304-306)."""
     tp = torch.from_numpy(patches).to(device=device, dtype=dtype)

@@ -60,3 +60,24 @@ def test_shard_ranges_cover():
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _solo_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from vtamiq_amd.dist import gather_scores
+    q = torch.arange(5, dtype=torch.float32)
+    same = gather_scores(q, 5)                                   # world of one: nothing to gather
+    forced = gather_scores(q, 5, force_collective=True)          # the collective itself on one rank
+    np.save(os.path.join(out_dir, "solo.npy"), np.stack([same.numpy(), forced.numpy()]))
+    assert same.data_ptr() == q.data_ptr() and forced.data_ptr() != q.data_ptr()
+    dist.destroy_process_group()
+
+
+def test_single_rank_forced_collective(tmp_path):
+    """bench.py's world-size-1 RCCL block: gather_scores(force_collective=True) runs the all-gather on ONE rank (gloo here)."""
+    mp.spawn(_solo_worker, args=(1, 29850 + (os.getpid() % 100), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "solo.npy"))
+    np.testing.assert_array_equal(got[0], np.arange(5, dtype=np.float32))
+    np.testing.assert_array_equal(got[1], got[0])

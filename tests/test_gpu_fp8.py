@@ -127,8 +127,8 @@ def test_gemm_fp8_residual(use_gamma):
     assert (x.double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
 
 
-def build(kw, sd_np):
-    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+def build(kw, sd_np, engine_options=0):
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8", engine_options=engine_options)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
     return m.to(DEV).eval()
 
@@ -332,7 +332,7 @@ def test_fp8_calibration_matches_the_oracles(name):
         assert torch.equal(model(p, ps, sc)[0], q)
 
 
-def test_fp8_static_scales_saturate_on_trained_like_weights_calibrated_ones_do_not(monkeypatch):
+def test_fp8_static_scales_saturate_on_trained_like_weights_calibrated_ones_do_not():
     """tests.helpers.stress_state (LayerNorm gains x8 on outlier channels, fc2 bias +2): the round-2 constants (LayerNorm x8, GELU x4)
     push values past e4m3's 448 -- clamped, and now REPORTED (error word bit 2) -- while scales calibrated on the batch do not."""
     from tests.helpers import stress_state
@@ -342,13 +342,11 @@ def test_fp8_static_scales_saturate_on_trained_like_weights_calibrated_ones_do_n
     sd = stress_state(spec, 9, qk=5.0, outlier=64.0)
     patches, pos, scales = synth.make_inputs(spec, 2, 80, 21)
     p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
-    monkeypatch.setenv("VTQ_FP8_STATIC_SCALES", "1")
-    m_static = build(kw, sd)
+    m_static = build(kw, sd, engine_options=_lib.OPT_FP8_STATIC_SCALES)
     with torch.no_grad():
         q_static = m_static(p, ps, sc)[0]
     with pytest.raises(FloatingPointError, match="clamped"):
         m_static.check_inputs()
-    monkeypatch.delenv("VTQ_FP8_STATIC_SCALES")
     m_cal = build(kw, sd)
     with torch.no_grad():
         q_cal = m_cal(p, ps, sc)[0]

@@ -29,6 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_config_struct_matches_header():
     from vtamiq_amd import _lib
     assert ctypes.sizeof(_lib.VtqConfig) == 20 * 4
+    assert _lib.VtqConfig.options.offset == 16 * 4            # include/vtamiq_hip.h: the field behind num_adapters
     assert ctypes.sizeof(_lib.VtqTensorDesc) == 24
 
 
@@ -239,3 +240,56 @@ def test_missing_pretrained_checkpoint_raises(monkeypatch, tmp_path):
         warnings.simplefilter("always")
         VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, vit_weights_path=missing))
     assert any("does not exist" in str(x.message) for x in w)
+
+
+MEASUREMENT_KNOBS = ["VTQ_GEMM_FLAGS", "VTQ_GEMM_CUS", "VTQ_GEMM_CG", "VTQ_GEMM_SCHED", "VTQ_GEMM_STAGGER", "VTQ_ATTN_LDS_PAD",
+                     "VTQ_ATTN_VARIANT", "VTQ_NO_CLS_PRUNE", "VTQ_FP8_STATIC_SCALES"]
+
+
+def test_product_library_reads_no_measurement_environment():
+    """the shipped library must not be steerable (or corruptible) through the environment.  Every measurement
+    knob is compiled in only with -DVTQ_MEASURE (tools/build_abl.sh); the product objects and the linked library contain neither the
+    variable names nor an undefined reference to getenv."""
+    import subprocess
+    from vtamiq_amd import _lib, build
+    build.build(verbose=False)
+    blobs = [_lib.LIB_PATH] + [os.path.join(build.OBJ, f) for f in os.listdir(build.OBJ) if f.endswith(".o")]
+    assert len(blobs) >= 2
+    for path in blobs:
+        data = open(path, "rb").read()
+        for knob in MEASUREMENT_KNOBS:
+            assert knob.encode() not in data, (os.path.basename(path), knob)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\bgetenv\b", nm), "libvtamiq_hip.so imports getenv"
+    # and in the sources every getenv of csrc/ goes through the VTQ_MEASURE_ENV gate
+    csrc = os.path.join(ROOT, "vtamiq_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            for line in open(os.path.join(csrc, f)):
+                if "getenv(" in line:
+                    assert "#define VTQ_MEASURE_ENV(name) getenv(name)" in line, (f, line.strip())
+
+
+def test_weight_signature_sees_replacement_and_new_storage():
+    """`p.data = new_tensor`, load_state_dict(assign=True) and module replacement must all change the signature the
+    engine's packed weights are keyed by (CPU-only: the signature is host logic)."""
+    from vtamiq_amd import VTAMIQ
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False), precision="bf16").eval()
+    s0 = m._signature()
+    assert m._signature() == s0
+    w = m.transformer.encoder.layers[0].attn.query.weight
+    w.data = w.data.clone() + 1.0                                   # new storage, version counter untouched
+    s1 = m._signature()
+    assert s1 != s0
+    sd = {k: v.clone() + 0.5 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)                              # new Parameter objects in every submodule
+    s2 = m._signature()
+    assert s2 != s1
+    m.transformer.encoder.layers[0].attn.query = torch.nn.Linear(768, 768)      # nested module replacement
+    s3 = m._signature()
+    assert s3 != s2
+    with torch.no_grad():
+        m.q_predictor[1].weight.add_(1.0)                           # in-place write: version counter
+    assert m._signature() != s3
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})        # copy_ into the same parameters
+    assert m._signature() != s3

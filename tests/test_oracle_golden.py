@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, STRESS_CASES, GOLDEN, load_case, split_inputs, rel_err
+from tests.helpers import E2E_CASES, LADDER_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
 import os
 
 # fp32 op-order differences between the restatement and the reference modules stay below this
@@ -42,6 +42,24 @@ def test_e2e_q_trained_like_statistics(name):
     q64 = O.vtamiq_forward(sd64, spec, p64, ps64, sc64)[0]
     assert q64.dtype == torch.float64
     assert rel_err(q64.numpy(), g["q64"])["max_rel"] < 1e-10
+
+
+@pytest.mark.parametrize("name", LADDER_CASES)
+def test_ladder_scores_at_baseline_patch_count(name):
+    """The oracle against the reference's fp32 and float64 scores of the 64-pair N = 500 ladder on trained-like weights (a bounded
+    sample here: the first 8 pairs in fp32 and in float64; the GPU test scores all 64).  float64: the same algorithm, 1e-10."""
+    g, kw, spec, sd, (patches, pos, scales) = load_ladder_case(name)
+    n = 8
+    p, ps, sc = split_inputs(patches[:n], pos[:n], None)
+    q = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)[0].numpy()
+    # fp32 against fp32 / fp64 of the reference in the gate's measure (raw relative for |q| >= 0.1 rms of the sample)
+    e32, e64 = gate_error(q, g["q"][:n]), gate_error(q, g["q64"][:n])
+    print(name, "oracle32-ref32", e32, "oracle32-ref64", e64)
+    assert e32 < 5e-4 and e64 < 5e-4, (e32, e64)
+    sd64 = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    p64, ps64, _ = split_inputs(patches[:n], pos[:n], None, dtype=torch.float64)
+    q64 = O.vtamiq_forward(sd64, spec, p64, ps64, (None, None))[0].numpy()
+    assert np.max(np.abs(q64 - g["q64"][:n])) < 1e-10 * np.sqrt(np.mean(g["q64"] ** 2)) + 1e-12
 
 
 def test_per_layer_tokens_c1():

@@ -2,7 +2,6 @@
 """Stage-by-stage comparison of the engine's fp8 mode with the fake-quant oracle on layer `--layer` of a golden case (GPU box).
 Uses the test hooks vtq_debug_stop_after / vtq_debug_buffers."""
 import argparse, ctypes as C, json, math, os, sys
-os.environ["VTQ_FP8_STATIC_SCALES"] = "1"      # this walk-through uses the oracle's static scales (F8.S_*): keep the engine on them too
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import torch.nn.functional as F
@@ -13,7 +12,7 @@ from vtamiq_amd import VTAMIQ, _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--case", default="c1_b2_n50"); ap.add_argument("--layer", type=int, default=0)
 a = ap.parse_args()
 g, kw, spec, sd, (patches, pos, scales) = load_case(a.case)
-m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8", engine_options=_lib.OPT_FP8_STATIC_SCALES)   # the oracle's static scales (F8.S_*)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
 p, ps, sc = split_inputs(patches, pos, scales, device="cuda")
 lib = _lib.load(); hip = C.CDLL("libamdhip64.so")

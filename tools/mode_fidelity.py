@@ -32,20 +32,11 @@ for wname in a.weights:
     state = {k: torch.from_numpy(v) for k, v in sd_np.items()}
 
     def make_model(prec):
-        static = prec == "fp8-static"
-        if static:
-            os.environ["VTQ_FP8_STATIC_SCALES"] = "1"       # the round-2 constants instead of the load-time calibration
-        try:
-            m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8" if static else prec)
-            m.load_state_dict(state)
-            m = m.to(dev).eval()
-            if prec.startswith("fp8"):                       # engine creation + weight load happen on the first forward: do it under the flag
-                inp = bench.synth_ladder_on_device(torch, 2, a.patches, dev, 1)
-                with torch.no_grad():
-                    m(*inp)
-        finally:
-            os.environ.pop("VTQ_FP8_STATIC_SCALES", None)
-        return m
+        static = prec == "fp8-static"                       # the round-2 constants instead of the calibration on the first batch
+        from vtamiq_amd import _lib
+        m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8" if static else prec, engine_options=_lib.OPT_FP8_STATIC_SCALES if static else 0)
+        m.load_state_dict(state)
+        return m.to(dev).eval()
     r = bench.mode_fidelity(torch, make_model, spec, sd_np, a.modes, dev, pairs=a.pairs, N=a.patches, threads=min(bench.effective_cores(), 64))
     print(f"weights = {wname}: rms(q_ref) = {r['rms_q_ref']:.4e}   (oracle: {r['oracle_seconds']:.0f} s)")
     for prec, c in r["modes"].items():

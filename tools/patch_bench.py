@@ -29,7 +29,7 @@ for nsc in (1, 3):
     print(f"8f-1 extract_patches: {NI} images {H}x{W}, {N} patches, {nsc} scale(s): {dt*1e3:.3f} ms / batch = {NI/2/dt:.0f} pairs/s "
           f"(~{byts/dt/1e12:.2f} TB/s of algorithmic traffic)")
 # ---- 8f-2: pairwise triplets, fused vs two calls
-m = VTAMIQ(vit_config=dict(variant="ViT-B16"), precision=os.environ.get("VTAMIQ_PRECISION", "fp16x3"))
+m = VTAMIQ(vit_config=dict(variant="ViT-B16", pretrained=False), precision=os.environ.get("VTAMIQ_PRECISION", "fp16x3"))
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(m.spec, 0).items()}); m = m.to(dev).eval()
 B = 32
 p = [torch.rand(B, N, 3, 16, 16, device=dev) * 2 - 1 for _ in range(3)]

@@ -20,7 +20,10 @@ NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
 MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
-ABI_VERSION = 4
+ABI_VERSION = 5
+OPT_FULL_LAST_LAYER = 1
+OPT_FP8_STATIC_SCALES = 2
+OPT_SEPARATE_LAYERNORM = 4
 
 KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]
 
@@ -28,8 +31,8 @@ KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "ou
 class VtqConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "hidden_size", "mlp_dim", "num_heads", "num_layers", "patch_dim", "pos_grid", "num_extra_tokens", "num_scales",
-        "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs", "ca_hidden", "precision", "num_adapters")] + [
-        ("reserved", C.c_int32 * 4)]
+        "use_layer_scale", "calibrate", "diff_scale", "num_rgs", "num_rcabs", "ca_hidden", "precision", "num_adapters", "options")] + [
+        ("reserved", C.c_int32 * 3)]
 
 
 class VtqTensorDesc(C.Structure):
@@ -102,14 +105,22 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+    # VTQ_LIB_PATH selects WHICH build is loaded (tools/build_abl.sh variants of this tree); it does not relax any check.  An A/B
+    # build of an OLDER tree (different ABI: argument layouts may differ) loads only with VTQ_ALLOW_ABI_MISMATCH=1, with a warning.
+    relaxed = os.environ.get("VTQ_ALLOW_ABI_MISMATCH") == "1"
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("VTQ_LIB_PATH") and not hasattr(lib, name):
-            continue                     # an A/B build of an older tree (tools/_abl, VTQ_LIB_PATH) may predate an entry point; the shipped library may not
+        if relaxed and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.vtq_abi_version() != ABI_VERSION and not os.environ.get("VTQ_LIB_PATH"):
-        raise RuntimeError("libvtamiq_hip.so ABI version mismatch")
+    if lib.vtq_abi_version() != ABI_VERSION:
+        if not relaxed:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {lib.vtq_abi_version()}, this package binds version {ABI_VERSION} "
+                               "(rebuild: python -m vtamiq_amd.build)")
+        import warnings
+        warnings.warn(f"{LIB_PATH}: ABI version {lib.vtq_abi_version()} != {ABI_VERSION} accepted (VTQ_ALLOW_ABI_MISMATCH=1): "
+                      "struct / argument layouts may differ -- measurement use only")
     _lib = lib
     return lib
 

@@ -1005,7 +1005,7 @@ template <typename T, int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
                               float out8_scale, Fp8Obs obs, bool q_log2) {
 #ifdef VTQ_ATTN_DIAG
-    static const int lds_pad = getenv("VTQ_ATTN_LDS_PAD") ? atoi(getenv("VTQ_ATTN_LDS_PAD")) : 0;   // occupancy experiments
+    static const int lds_pad = VTQ_MEASURE_ENV("VTQ_ATTN_LDS_PAD") ? atoi(VTQ_MEASURE_ENV("VTQ_ATTN_LDS_PAD")) : 0;   // occupancy experiments
     const int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2) + lds_pad;
 #else
     constexpr int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2);
@@ -1086,7 +1086,7 @@ bool attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
 }
 
 static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
-    static const int env = getenv("VTQ_ATTN_VARIANT") ? atoi(getenv("VTQ_ATTN_VARIANT")) : -1;
+    static const int env = VTQ_MEASURE_ENV("VTQ_ATTN_VARIANT") ? atoi(VTQ_MEASURE_ENV("VTQ_ATTN_VARIANT")) : -1;   // -DVTQ_MEASURE builds only
     const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
     if (forced >= 0) return forced == 1;
     return attention_rule(nseq, S_pad, H, terms, cus);

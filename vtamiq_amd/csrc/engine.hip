@@ -49,7 +49,7 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 // every point on that batch -- each producing kernel reports it (kernels.h Fp8Obs) and is run again once its scale is chosen, so
 // everything downstream already sees the final operands -- and takes the largest power of two that maps it to <= 224 (a factor two
 // of headroom for other batches; e4m3 is a floating format, so headroom costs no precision until values underflow 2^-9).
-// VTQ_FP8_STATIC_SCALES=1 keeps the constants.  A value that still exceeds 448 after scaling is clamped and raises bit 2 of the
+// vtq_config.options & VTQ_OPT_FP8_STATIC_SCALES keeps the constants.  A value that still exceeds 448 after scaling is clamped and raises bit 2 of the
 // error word (vtq_input_errors).
 constexpr float kSPatch = 256.0f, kSLn = 8.0f, kSAtt = 16.0f, kSGelu = 4.0f;
 constexpr float kFp8Target = 224.0f;
@@ -100,6 +100,7 @@ struct vtq_engine {
     float s_patch = kSPatch;           //   activation scales (see kSPatch ...): patches, then per layer {LN1, attention, LN2, GELU}
     std::vector<float> s_ln1, s_att, s_ln2, s_gelu;
     bool fp8_static = false, fp8_calibrated = false, calibrating = false;
+    bool fp8_installed = false;        //   the current scales came from vtq_fp8_set_scales: a weight reload keeps them
     float* amax_slot = nullptr;        //   device word the producers report max |value| into during a calibration forward
     float* spatch = nullptr;           //   inverse weight scales of the patch embedding
     int64_t PDp = 0;                   // patch_dim rounded up to the GEMM's K granule (row pitch of the packed patches / weight)
@@ -721,9 +722,9 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     e->H = c.hidden_size;
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
-    { const char* np = getenv("VTQ_NO_CLS_PRUNE"); e->cls_prune = !(np && np[0] == '1'); }
+    e->cls_prune = !(c.options & VTQ_OPT_FULL_LAST_LAYER);
     e->s_ln1.assign(c.num_layers, kSLn); e->s_att.assign(c.num_layers, kSAtt); e->s_ln2.assign(c.num_layers, kSLn); e->s_gelu.assign(c.num_layers, kSGelu);
-    { const char* st = getenv("VTQ_FP8_STATIC_SCALES"); e->fp8_static = st && st[0] == '1'; }
+    e->fp8_static = (c.options & VTQ_OPT_FP8_STATIC_SCALES) != 0;
     if (hipMalloc((void**)&e->err_flag, 16) != hipSuccess || hipMemset(e->err_flag, 0, 16) != hipSuccess) {
         vtq_destroy(e);
         return fail("vtq_create: device allocation failed");
@@ -785,6 +786,9 @@ int vtq_load_weights(vtq_handle e, const vtq_tensor_desc* descs, int32_t n, void
     }
     if (pack_head(e, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
+    // fp8 mode: scales calibrated on the previous weights do not fit these (activations would clamp at +-448): the next forward
+    // calibrates again -- unless the caller installed the scales itself (a checkpoint that carries them; vtq_fp8_set_scales)
+    if (e->fp8 && !e->fp8_installed) e->fp8_calibrated = false;
     return 0;
 }
 
@@ -944,6 +948,7 @@ int vtq_fp8_calibrate(vtq_handle e, const float* patches_ref, const float* patch
                       const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
     if (!e || !e->fp8) return fail("vtq_fp8_calibrate: not an fp8 engine");
     e->fp8_calibrated = false;
+    e->fp8_installed = false;
     const bool was_static = e->fp8_static;
     e->fp8_static = false;
     const int rc = vtq_forward(e, patches_ref, patches_dist, pos_ref, pos_dist, scales_ref, scales_dist, B, N, q_out, stream);
@@ -974,6 +979,7 @@ int vtq_fp8_set_scales(vtq_handle e, const float* in, int32_t n) {
     e->s_patch = in[0];
     for (int i = 0; i < L; ++i) { e->s_ln1[i] = in[1 + 4 * i]; e->s_att[i] = in[2 + 4 * i]; e->s_ln2[i] = in[3 + 4 * i]; e->s_gelu[i] = in[4 + 4 * i]; }
     e->fp8_calibrated = true;
+    e->fp8_installed = true;
     return 0;
 }
 

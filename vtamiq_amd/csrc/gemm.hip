@@ -404,8 +404,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 //   sake; the first group issued AFTER the stores (g2) is waited for one K tile later.
 //
 // Half tiles (128 x 256, rows of A half 0 only) are phase A alone: one group {A0, W0, W1} per K tile on a ring of THREE
-// 48 KiB buffers, tile kt+2 staged in phase kt into the buffer read in phase kt-1 (same WAR/RAW argument).  They close a
-// workgroup's list (build_schedule) and take no part in the cross-tile prefetch.
+// 48 KiB buffers, tile kt+2 staged in phase kt into the buffer read in phase kt-1 (same WAR/RAW argument).  They take no part in
+// the cross-tile prefetch: a half tile is entered and left with `chained == false`, so it stages its own K tiles from scratch and the
+// tile after it starts through the unchained entry path.  build_schedule puts them at the END of a workgroup's list, or -- the
+// epilogue stagger on the odd XCDs -- a single closing half tile at the FRONT; the half -> full transition is safe because the half
+// tile's epilogue ends with the lgkmcnt(0) + barrier below (its LDS images are retired) and its stores are OLDER than the next tile's
+// first DMA group: the in-order vmcnt of the unchained entry (wait_vm<GO + GE>) retires them together with that group.
 template <typename T, int TERMS, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     typedef typename Vec<T>::x8 tx8;                 // one MFMA operand fragment: 16 bytes (16-bit forms) / 32 bytes (fp8)
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         const int tm = tile / ntn, tn = tile - tm * ntn;
         const int64_t m0 = (int64_t)tm * 256 + (kind == 2 ? kHalfRows : 0);
         const int n0 = tn * 256;
-        const bool wrapl = (p.flags & GEMM_FLAG_WRAP_LOADS) != 0;     // measurement: every tile reads the first two A / W panels (L2 hits)
+        const bool wrapl = (gemm_flags(p) & GEMM_FLAG_WRAP_LOADS) != 0;     // measurement: every tile reads the first two A / W panels (L2 hits)
         const T* __restrict__ Ag = (const T*)p.A + (wrapl ? (m0 & 511) : m0) * p.lda;
         const T* __restrict__ Wg = (const T*)p.W + (int64_t)(wrapl ? (n0 & 511) : n0) * p.K;
         // the next entry of this workgroup's list, if the DMA ring may run on into it
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         const T* Wgn = Wg;
         bool has_next = false;
         if constexpr (kChain) {
-            if (kind == 0 && it + 1 < it_end && !(p.flags & GEMM_FLAG_NO_CHAIN)) {
+            if (kind == 0 && it + 1 < it_end && !(gemm_flags(p) & GEMM_FLAG_NO_CHAIN)) {
                 const int dn = sch[it + 1];
                 if ((dn & 3) == 0) {
                     const int tmn = (dn >> 2) / ntn, tnn = (dn >> 2) - tmn * ntn;
@@ -692,8 +696,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
             VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();        // match the extra barrier of the second group
-            if (!(p.flags & GEMM_FLAG_NO_EPILOGUE))
-                pp_epilogue<TO, OPL, EPI, 2, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
+            if (!(gemm_flags(p) & GEMM_FLAG_NO_EPILOGUE))
+                pp_epilogue<TO, OPL, EPI, 2, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (gemm_flags(p) & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             }
             VTQ_DIAG_LOOP_END()
             if (wr == 0) __builtin_amdgcn_s_barrier();
-            pp_epilogue<TO, OPL, EPI, 1, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (p.flags & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
+            pp_epilogue<TO, OPL, EPI, 1, F8, kBiasInAcc>(p, acc, smem, tid, wr, wc, fr, fq, (gemm_flags(p) & GEMM_FLAG_WRAP_ROWS) ? 0 : m0, n0, epi_diag);
             chained = false;
             if (it + 1 < it_end) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -798,7 +802,7 @@ constexpr int kXcds = 8, kCusPerXcd = 32, kNumCus = kXcds * kCusPerXcd;
 constexpr double kHalfCost = 0.57;
 
 int cus_per_xcd() {
-    static const int n = [] { const char* v = getenv("VTQ_GEMM_CUS"); const int k = v ? atoi(v) : kCusPerXcd; return (k >= 1 && k <= kCusPerXcd) ? k : kCusPerXcd; }();
+    static const int n = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_CUS"); const int k = v ? atoi(v) : kCusPerXcd; return (k >= 1 && k <= kCusPerXcd) ? k : kCusPerXcd; }();
     return n;                                    // measurement knob: workgroups per XCD of the persistent launch (default: all 32 CUs)
 }
 
@@ -819,7 +823,7 @@ double greedy_makespan(int n_full, int n_half) {
 
 // entries of one XCD owning `order[0..cnt)`: whole tiles, then `tail` tiles as top/bottom halves
 void xcd_sequence(const int* order, int cnt, std::vector<int>& out) {
-    static const bool all_halves = [] { const char* v = getenv("VTQ_GEMM_SCHED"); return v && v[0] == '2'; }();   // measurement knob
+    static const bool all_halves = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_SCHED"); return v && v[0] == '2'; }();   // measurement knob
     int best_tail = 0;
     double best = 1e30;
     for (int tail = 0; tail <= cnt && tail <= 2 * kCusPerXcd; ++tail) {
@@ -858,8 +862,8 @@ std::vector<int> build_schedule(int ntm, int ntn, int cg) {
     // workgroup of the chip reaches its epilogue -- a burst of stores and, in the residual form, loads -- at the same moments; with the
     // half tile in front, the odd XCDs' epilogues fall about half a tile after the even ones'.  Whole XCDs, not every second CU of one:
     // the column tiles of a row panel that share their A panel through the XCD's L2 stay in step (per-CU staggering cost fc2 3.5 %).
-    // Same work, same results (profiles/r03_gemm_stagger.txt: out-proj -6 %, QKV -3 %, fc2 and fc1 unchanged; VTQ_GEMM_STAGGER=0: off).
-    static const bool stagger = [] { const char* v = getenv("VTQ_GEMM_STAGGER"); return !(v && v[0] == '0'); }();
+    // Same work, same results (profiles/r03_gemm_stagger.txt: out-proj -6 %, QKV -3 %, fc2 and fc1 unchanged; -DVTQ_MEASURE builds: VTQ_GEMM_STAGGER=0 turns it off).
+    static const bool stagger = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_STAGGER"); return !(v && v[0] == '0'); }();
     if (stagger)
         for (int b = 0; b < kNumCus; ++b) {
             std::vector<int>& l = lists[b];
@@ -938,7 +942,7 @@ hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds, hi
 }
 
 int env_cg() {
-    static const int v = [] { const char* c = getenv("VTQ_GEMM_CG"); return c ? atoi(c) : 0; }();    // measurement knob: column-group width of the tile order
+    static const int v = [] { const char* c = VTQ_MEASURE_ENV("VTQ_GEMM_CG"); return c ? atoi(c) : 0; }();    // measurement knob: column-group width of the tile order
     return v;
 }
 
@@ -946,7 +950,7 @@ unsigned long long* g_diag_buf = nullptr;      // diagnostic builds: stamp buffe
 int g_diag_shadow = 0;
 
 int env_flags() {
-    static const int f = [] { const char* v = getenv("VTQ_GEMM_FLAGS"); return v ? atoi(v) : 0; }();   // measurement knobs (kernels.h)
+    static const int f = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_FLAGS"); return v ? atoi(v) : 0; }();   // measurement knobs (kernels.h)
     return f;
 }
 

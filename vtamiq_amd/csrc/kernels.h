@@ -25,7 +25,16 @@ inline bool num_valid(Num n) {
     return (n.terms == 1 || n.terms == 3 || (n.terms == 2 && n.f16 == 1)) && (n.f16 == 0 || n.f16 == 1);
 }
 
-// GemmArgs::flags, measurement knobs (environment VTQ_GEMM_FLAGS, read once per process)
+// Measurement knobs.  The PRODUCT library reads no environment variable and executes no measurement branch: every knob below exists only
+// in builds with -DVTQ_MEASURE (tools/build_abl.sh), where VTQ_MEASURE_ENV is getenv; in the shipped build it is a null constant (the
+// variable names do not even appear in the objects: tests/test_layout.py greps for them) and GemmArgs::flags is ignored by the kernels.
+#ifdef VTQ_MEASURE
+#define VTQ_MEASURE_ENV(name) getenv(name)
+#else
+#define VTQ_MEASURE_ENV(name) ((const char*)nullptr)
+#endif
+
+// GemmArgs::flags, measurement knobs (-DVTQ_MEASURE builds: environment VTQ_GEMM_FLAGS, read once per process)
 enum { GEMM_FLAG_WRAP_ROWS = 1,     // every tile writes the rows of row panel 0: no HBM write stream (timing experiments only)
        GEMM_FLAG_NO_CHAIN = 2,      // no DMA chaining across a workgroup's consecutive tiles
        GEMM_FLAG_DYNAMIC = 4,       // one schedule entry per workgroup, as many workgroups as entries (hardware dispatch order
@@ -64,12 +73,18 @@ struct GemmArgs {
     const float* wscale; float ascale_inv; float out_scale;
     Fp8Obs obs;                                   // fp8 GELU form only (the one GEMM epilogue that writes e4m3 bytes)
     const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
-    int flags;                                    // set by launch_gemm: GEMM_FLAG_*
+    int flags;                                    // set by launch_gemm: GEMM_FLAG_* (-DVTQ_MEASURE builds; the product kernels read 0, gemm_flags())
     // diagnostic builds (-DVTQ_GEMM_DIAG, tools/build_abl.sh) only; set by launch_gemm from gemm_set_diag, never read otherwise:
     unsigned long long* diag;                     //   per workgroup 8 words: K-loop and whole-kernel s_memtime / s_memrealtime sums
     int shadow;                                   //   dummy v_fma_f32 issued in every load phase (x8): the price of VALU work beside the partner's MFMAs
     float* row_stats;                             //   -DVTQ_RESID_PLANES pricing build only: per row and column tile (mean, M2) of the new residual row
 };
+
+#ifdef VTQ_MEASURE
+__host__ __device__ inline int gemm_flags(const GemmArgs& a) { return a.flags; }
+#else
+__host__ __device__ constexpr int gemm_flags(const GemmArgs&) { return 0; }
+#endif
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches

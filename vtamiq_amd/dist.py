@@ -19,11 +19,14 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_scores(q_local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+def gather_scores(q_local: torch.Tensor, global_batch: int, group=None, force_collective: bool = False) -> torch.Tensor:
     """All ranks receive q[global_batch] in global pair order.  Uneven shards are padded to the largest shard so the
-    collective stays a single fixed-size all-gather."""
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    if world == 1:
+    collective stays a single fixed-size all-gather.  A single-rank world returns its scores as they are, unless
+    `force_collective` (an initialised process group of size 1): then the same all_gather_into_tensor runs on one rank --
+    library load, communicator init and stream ordering of the RCCL path exercised on a 1-GPU box (bench.py --force-collective)."""
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    if world == 1 and not (force_collective and initialised):
         return q_local
     per = -(-global_batch // world)
     send = q_local
@@ -45,3 +48,14 @@ def sharded_forward(model, patches, pos, scales, global_batch: int, group=None) 
     """Run the model on this rank's shard (inputs are the LOCAL shard) and return the gathered global scores."""
     q_local, _ = model(patches, pos, scales)
     return gather_scores(q_local, global_batch, group)
+
+
+def broadcast_fp8_scales(model, src: int = 0, group=None) -> None:
+    """fp8 mode: every rank calibrates its activation scales on its OWN shard's first batch, so the ranks of a data-parallel job
+    would score with different scales.  Call this once after the first forward (or after calibrate_fp8 on rank `src`): rank
+    `src`'s scales are installed on every rank (model.set_fp8_scales), which also keeps them across weight reloads."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    box = [model.fp8_scales() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    model.set_fp8_scales(box[0])

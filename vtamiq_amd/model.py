@@ -32,6 +32,19 @@ _PRECISIONS = _lib.PRECISIONS
 DEFAULT_PRECISION = "auto"
 AUTO_FIRST, AUTO_FALLBACK = "fp16x3", "bf16x3"
 
+# Structure epoch: bumped whenever ANY module registers a parameter or a submodule (load_state_dict(assign=True), `m.sub = new`,
+# `m.weight = nn.Parameter(...)` all go through register_parameter / register_module).  A model whose cached parameter list was
+# taken in an older epoch walks its tree again; the cached walk is otherwise valid (replacement must not go unseen).
+_STRUCT_EPOCH = [0]
+
+
+def _bump_epoch(*_a, **_k):
+    _STRUCT_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+
 
 class _Params(nn.Module):
     """A container whose forward must never run."""
@@ -149,8 +162,10 @@ def _residual_group(H, hid, num_rcabs):     # ResidualGroup.body (channel_attent
 
 class VTAMIQ(nn.Module):
     def __init__(self, vit_config=None, calibrate=True, diff_scale=True, num_rgs=4, num_rcabs=4, rg_path_drop=0.1,
-                 ca_reduction=8, predictor_dropout=0., return_features=False, precision: Optional[str] = None, **kwargs):
+                 ca_reduction=8, predictor_dropout=0., return_features=False, precision: Optional[str] = None,
+                 engine_options: int = 0, **kwargs):
         super().__init__()
+        self.engine_options = int(engine_options)      # vtq_config.options (_lib.OPT_*): tests and A/B measurement; 0 = product path
         for k, v in kwargs.items():         # reference only warns about unknown kwargs (vtamiq.py:49)
             warnings.warn(f"[VTAMIQ] Unused kwarg [{k}={v}]")
         vit_config = dict(vit_config or {})
@@ -252,14 +267,17 @@ class VTAMIQ(nn.Module):
 
     # ---- engine management --------------------------------------------------------------------------------
     def _signature(self):
-        ps = self.__dict__.get("_param_cache")
-        if ps is None:                               # the parameter OBJECTS are fixed after construction (.to() / load_state_dict
-            ps = list(self.parameters())             # write into them): walk the module tree once, not on every forward
-            self.__dict__["_param_cache"] = ps
-        # version counters only grow, so their sum changes iff any parameter was written in place (load_state_dict, optimizer-style
-        # ops); storage replacement goes through _apply (.to() / .cuda()), which resets the packed state itself.  One attribute read per
-        # parameter: this runs on every forward, and with precision="auto" the device waits for the host between forwards.
-        return sum(p._version for p in ps)
+        """What the packed engine weights were made from: identity, storage and version of every parameter.  The module tree is
+        walked only when some module registered a parameter / submodule since the last walk (_STRUCT_EPOCH: parameter or module
+        REPLACEMENT, load_state_dict(assign=True)); the per-forward part is (data_ptr, _version) of the cached list, which sees
+        `p.data = new_tensor` (new storage) and every in-place write that bumps the version counter (load_state_dict, optimizers).
+        Not seen: in-place edits through `.data` (p.data.copy_()) -- refresh_weights()."""
+        cache = self.__dict__.get("_param_cache")
+        if cache is None or cache[0] != _STRUCT_EPOCH[0]:
+            cache = (_STRUCT_EPOCH[0], list(self.parameters()))
+            self.__dict__["_param_cache"] = cache
+        ps = cache[1]
+        return (tuple(map(id, ps)), tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps))
 
     def _release_engine(self):
         eng = self.__dict__.get("_engine")
@@ -320,16 +338,41 @@ class VTAMIQ(nn.Module):
         if self.precision == "auto":
             flags = self._read_flags()
             if flags & 2 and not self._auto_fallback:
-                warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
-                              f"{AUTO_FIRST!r}: this model now runs {AUTO_FALLBACK!r} (fp32 operand range, the same 3-MFMA split; "
-                              "the call is repeated)")
+                # Either an operand left the fp16 range (the checkpoint's activation scale: bf16x3 cures it, and the switch stays), or
+                # the inputs / weights hold inf / NaN (nothing cures that).  Run the call again in bf16x3 and look.
                 self._auto_fallback = True
                 launch(self._ensure_engine(device))
-                flags = (flags & 1) | self._read_flags()
+                flags2 = self._read_flags()
+                if flags2 & 2:
+                    # still non-finite with the fp32 operand range: the DATA is non-finite, not the format too narrow.  Go back to
+                    # the parity mode (one bad batch must not leave the model in bf16x3 for good) and hand the caller
+                    # what the reference's fp32 forward returns for such inputs: NaN scores (train.py:602-607), loudly.
+                    self._auto_fallback = False
+                    warnings.warn("[VTAMIQ] non-finite scores: the inputs or weights of this call hold inf / NaN (both the fp16x3 and "
+                                  "the bf16x3 forward overflowed); the model stays in precision 'fp16x3'")
+                else:
+                    warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
+                                  f"{AUTO_FIRST!r}: this model now runs {AUTO_FALLBACK!r} (fp32 operand range, the same 3-MFMA "
+                                  "split; the call was repeated)")
+                flags = (flags & 1) | (flags2 & 1)
+            elif flags & 2:
+                warnings.warn("[VTAMIQ] non-finite scores in precision 'bf16x3': the inputs or weights of this call hold inf / NaN")
             if flags & 1:
                 raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
-            if flags & 2:
-                raise FloatingPointError("non-finite encoder output in precision 'bf16x3': the inputs or weights hold inf / NaN")
+        elif self.engine_precision == "fp8":
+            # the first forward calibrated the activation scales on its batch: remember them (a re-created engine gets them back), and
+            # look at the saturation bit on the first few forwards -- an asynchronous fp8 model must not clamp at +-448 unnoticed
+            if self.__dict__.get("_fp8_saved") is None:
+                self.fp8_scales()
+            n = self.__dict__.get("_fp8_checked", 0)
+            if n < 3 or self.validate_inputs:
+                self.__dict__["_fp8_checked"] = n + 1
+                flags = self._read_flags()
+                if flags & 4:
+                    warnings.warn("[VTAMIQ] fp8 mode: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
+                                  "activation scales do not fit this data; calibrate_fp8() on a representative batch")
+                if flags & 1:
+                    raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
         elif self.validate_inputs:
             self.check_inputs()
 
@@ -344,11 +387,13 @@ class VTAMIQ(nn.Module):
                 patch_dim=s.patch_dim, pos_grid=s.pos_grid, num_extra_tokens=s.num_extra_tokens,
                 num_scales=s.num_scales if s.use_scale_embedding else 0, use_layer_scale=int(s.use_layer_scale),
                 calibrate=int(s.calibrate), diff_scale=int(s.diff_scale), num_rgs=s.num_rgs, num_rcabs=s.num_rcabs,
-                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.engine_precision], num_adapters=s.num_adapters)
+                ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.engine_precision], num_adapters=s.num_adapters,
+                options=self.engine_options)
             h = C.c_void_p()
             _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
             self._engine, self._engine_device, self._engine_precision = h, device, self.engine_precision
             self._weights_sig = None
+            self.__dict__["_fp8_reinstall"] = self.__dict__.get("_fp8_saved") is not None
         sig = self._signature()
         if sig != self._weights_sig:
             sd = self.state_dict()
@@ -365,8 +410,15 @@ class VTAMIQ(nn.Module):
                 keep.append(t)
                 descs[i] = _lib.VtqTensorDesc(k.encode(), t.data_ptr(), t.numel())
             stream = torch.cuda.current_stream(device).cuda_stream
+            if self._weights_sig is not None and not self.__dict__.get("_fp8_user"):
+                self.__dict__["_fp8_saved"] = None      # other weights: scales calibrated on the old ones are dropped (the engine recalibrates)
             _lib.check(lib.vtq_load_weights(self._engine, descs, len(names), stream))
             self._weights_sig = sig
+        if self.__dict__.get("_fp8_reinstall") and self.engine_precision == "fp8":
+            # a re-created engine (.to(), device change) keeps the scales this model already ran with instead of calibrating on
+            # whatever batch comes next: fp8 scores stay reproducible across engine lifetimes
+            self.__dict__["_fp8_reinstall"] = False
+            self._install_fp8(self.__dict__["_fp8_saved"])
         return lib
 
     def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameter storage (possibly the objects) is replaced
@@ -478,15 +530,28 @@ class VTAMIQ(nn.Module):
         lib.vtq_fp8_get_scales(self._engine, buf, n)
         v = list(buf)
         L = (n - 1) // 4
-        return {"patch": v[0], "ln1": v[1::4][:L], "att": v[2::4][:L], "ln2": v[3::4][:L], "gelu": v[4::4][:L]}
+        sc = {"patch": v[0], "ln1": v[1::4][:L], "att": v[2::4][:L], "ln2": v[3::4][:L], "gelu": v[4::4][:L]}
+        if not self.__dict__.get("_fp8_user"):
+            self.__dict__["_fp8_saved"] = sc            # what a re-created engine gets back (see _ensure_engine)
+        return sc
 
-    def set_fp8_scales(self, sc):
+    def _install_fp8(self, sc):
         L = len(sc["ln1"])
         flat = [sc["patch"]]
         for i in range(L):
             flat += [sc["ln1"][i], sc["att"][i], sc["ln2"][i], sc["gelu"][i]]
         buf = (C.c_float * len(flat))(*flat)
         _lib.check(_lib.load().vtq_fp8_set_scales(self._engine, buf, len(flat)))
+
+    def set_fp8_scales(self, sc):
+        """Install activation scales (the dict fp8_scales() returns, e.g. from a checkpoint's side file or from rank 0:
+        dist.broadcast_fp8_scales).  Installed scales survive weight reloads and engine re-creation; calibrate_fp8() replaces them."""
+        if self.precision != "fp8":
+            raise RuntimeError("set_fp8_scales: precision is not 'fp8'")
+        self.__dict__["_fp8_saved"] = {k: (list(v) if isinstance(v, (list, tuple)) else float(v)) for k, v in sc.items()}
+        self.__dict__["_fp8_user"] = True
+        if self._engine is not None:
+            self._install_fp8(self.__dict__["_fp8_saved"])
 
     def calibrate_fp8(self, patches, pos, scales):
         """Re-calibrate the fp8 activation scales on this batch (arguments as forward()); returns the batch's scores."""
@@ -504,6 +569,8 @@ class VTAMIQ(nn.Module):
             _lib.check(lib.vtq_fp8_calibrate(self._engine, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
                                              sc[0].data_ptr() if use_scales else None, sc[1].data_ptr() if use_scales else None,
                                              B, N, q.data_ptr(), stream))
+        self.__dict__["_fp8_user"] = False
+        self.fp8_scales()                               # remembered for engine re-creation
         return q
 
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------

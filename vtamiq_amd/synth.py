@@ -87,3 +87,34 @@ def make_inputs(spec: ModelSpec, B: int, N: int, seed: int = 1234, aligned: bool
         ids = np.concatenate([np.full(c, i, dtype=np.int32) for i, c in enumerate(counts)])[:N]
         scales = np.broadcast_to(ids[None, None, :], (B, 2, N)).astype(np.int32).copy()
     return patches, pos, scales
+
+
+LADDER_SIGMAS = (0.02, 0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5)
+
+
+def make_ladder_inputs(spec: ModelSpec, images: int, N: int, seed: int = 777, sigmas=LADDER_SIGMAS
+                       ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+    """A distortion ladder as an IQA test set has one: `images` reference patch sets, each paired with len(sigmas) distorted
+    versions dist = clamp(ref + sigma N(0,1)) -> images * len(sigmas) pairs in the collated layout of make_inputs (pair
+    i*len(sigmas) + j = image i at sigmas[j]); positions shared by ref and dist (aligned sampling).  Host-side twin of bench.py's
+    on-device ladder, seeded through numpy so that the golden capture (build container) and the GPU tests see the same tensors."""
+    P = spec.patch_size
+    S = len(sigmas)
+    r = _rs(seed, f"ladder/{images}/{N}")
+    ref = r.uniform(-1.0, 1.0, size=(images, N, 3, P, P)).astype(np.float32)
+    pos = np.minimum(r.uniform(0.0, 1.0, size=(images, N, 2)).astype(np.float32), np.float32(1.0 - 1e-6))
+    B = images * S
+    patches = np.empty((B, 2, N, 3, P, P), dtype=np.float32)
+    posb = np.empty((B, 2, N, 2), dtype=np.float32)
+    for i in range(images):
+        for j, sg in enumerate(sigmas):
+            noise = r.normal(size=ref[i].shape).astype(np.float32)
+            patches[i * S + j, 0] = ref[i]
+            patches[i * S + j, 1] = np.clip(ref[i] + np.float32(sg) * noise, -1.0, 1.0)
+            posb[i * S + j, :] = pos[i]
+    scales = None
+    if spec.use_scale_embedding:
+        counts = num_patches_per_scale(N, spec.num_scales)
+        ids = np.concatenate([np.full(c, i, dtype=np.int32) for i, c in enumerate(counts)])[:N]
+        scales = np.broadcast_to(ids[None, None, :], (B, 2, N)).astype(np.int32).copy()
+    return patches, posb, scales
