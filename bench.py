@@ -339,6 +339,12 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a.gpus, sys.argv[1:], a.launch_timeout))
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner sits in libc's buffer until exit and
+    # lands BEHIND the line): from here on file descriptor 1 is stderr, and the line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -448,12 +454,12 @@ def main():
         dt, q, _ = run(StubModel(), a.steps, a.warmup)
         assert q.shape == (global_batch,)
         if rank == 0:
-            print(json.dumps({"metric": "launcher self-test (stub model, no HIP)", "value": global_batch * a.steps / dt,
+            print(file=real_stdout, flush=True, *[json.dumps({"metric": "launcher self-test (stub model, no HIP)", "value": global_batch * a.steps / dt,
                               "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f32", "data": "stub", "rccl_ranks": rccl_ranks, "backend": a.backend,
                               "config": {"workload": "stub", "global_batch": global_batch, "parallelism": f"dp{world}"},
-                              "q_checksum": float(q.double().sum())}), flush=True)
+                              "q_checksum": float(q.double().sum())})])
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -682,7 +688,7 @@ def main():
                                                          "run: busy SIMD-cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)")
             else:
                 out["roofline"]["traffic_live_error"] = src
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

@@ -195,6 +195,16 @@ int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int6
                 const float* bias, const float* gamma, float* x_f32,
                 void* out16, int64_t o_plane, int32_t ldo, void* stream);
 
+/* Whole-row residual GEMM with LayerNorm in its epilogue (csrc/gemm_rowln.hip; N = 768, num = VTQ_NUM_BF16X3 | VTQ_NUM_FP16X3, M % 128 == 0,
+ * K % 32 == 0, K >= 128):
+ *     x_f32[M, 768] += gamma * (A[M, K] * W[768, K]^T + bias)          (out-proj / fc2 + LayerScale + residual, transformer.py:279, 284)
+ *     out16 planes   = LayerNorm(x_f32; ln_w, ln_b, eps 1e-6)           (the NEXT block's attention_norm / ffn_norm, transformer.py:276, 281)
+ * in one launch: the workgroup that owns a 128-row panel owns whole rows.  ln_w == NULL: no LayerNorm output (the x update only).
+ * x_f32 is bit-identical to vtq_k_gemm epilogue 2, out16 to vtq_k_layernorm applied to it. */
+int  vtq_k_gemm_rowln(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t K, int32_t num,
+                      const float* bias, const float* gamma, float* x_f32, const float* ln_w, const float* ln_b,
+                      void* out16, int64_t o_plane, void* stream);
+
 /* fp8 (VTQ_PREC_FP8) building blocks.  vtq_k_quant_rows_fp8: W[N][K] fp32 -> e4m3 rows, each scaled by the largest power of two
  * that keeps its maximum <= 448, inv_scale[n] = 1 / scale.  vtq_k_quant_fp8: e4m3(src * scale), clamped to +-448.
  * vtq_k_gemm_fp8: C = A8[M,K] * W8[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), acc * wscale[n] * ascale_inv,

@@ -113,6 +113,63 @@ def test_gemm_residual(fmt, use_gamma, M):
     assert (x[rows].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("fmt", ["fp16x3", "bf16x3"])
+@pytest.mark.parametrize("M,K", [(128, 768), (256 * 5, 768), (128 * 3, 3072), (128 * 259, 768), (128 * 257, 128), (128 * 2, 96 + 32)])
+@pytest.mark.parametrize("use_gamma,use_ln", [(True, True), (False, True), (True, False)])
+def test_gemm_rowln_is_the_two_launch_path_bit_for_bit(fmt, M, K, use_gamma, use_ln):
+    """The whole-row residual GEMM with LayerNorm in its epilogue (gemm_rowln.hip) against the path it replaces -- vtq_k_gemm epilogue 2
+    (x += gamma * (A W^T + bias)) followed by vtq_k_layernorm -- BITWISE: the accumulation order per element and the LayerNorm arithmetic
+    are the same by construction.  Shapes: one tile, several tiles, K = 3072 (fc2), more tiles than CUs (a workgroup walks two), the
+    smallest K the kernel takes (4 K tiles) -- and the two-launch path is itself checked against fp64 by test_gemm_residual / test_layernorm."""
+    lib = _lib.load()
+    N = 768
+    Mp = (M + 255) // 256 * 256                                # the 256 x 256 kernel needs M % 256 == 0; the row kernel M % 128 == 0
+    A, W, bias = _randn(Mp, K, seed=21), _randn(N, K, seed=22, scale=0.03), _randn(N, seed=23)
+    gamma = _randn(N, seed=24) + 1.0 if use_gamma else None
+    lw, lb = _randn(N, seed=25) + 1.0, _randn(N, seed=26)
+    x0 = _randn(Mp, N, seed=27, scale=2.0)
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    x_ref = x0.clone()
+    _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), Mp * K, K, Wp.data_ptr(), N * K, Mp, N, K, num_code(fmt), 2, bias.data_ptr(),
+                              gamma.data_ptr() if use_gamma else None, x_ref.data_ptr(), None, 0, 0, stream()))
+    out_ref = torch.zeros((2, Mp, N), dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_layernorm(x_ref.data_ptr(), lw.data_ptr(), lb.data_ptr(), out_ref.data_ptr(), Mp * N, Mp, N, FORMATS[fmt][0], 2, stream()))
+    x = x0.clone()
+    out = torch.full((2, Mp, N), 7.0, dtype=elt_dtype(fmt), device=DEV)
+    _lib.check(lib.vtq_k_gemm_rowln(Ap.data_ptr(), Mp * K, K, Wp.data_ptr(), N * K, M, K, num_code(fmt), bias.data_ptr(),
+                                    gamma.data_ptr() if use_gamma else None, x.data_ptr(), lw.data_ptr() if use_ln else None,
+                                    lb.data_ptr() if use_ln else None, out.data_ptr() if use_ln else None, Mp * N, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(x[:M], x_ref[:M])
+    assert torch.equal(x[M:], x0[M:])                          # rows beyond M untouched
+    if use_ln:
+        assert torch.equal(out[:, :M].view(torch.int16), out_ref[:, :M].view(torch.int16))
+    assert bool((out[:, M:] == 7.0).all())
+    if not use_ln:
+        assert bool((out == 7.0).all())
+
+
+def test_gemm_rowln_repeats_bit_for_bit():
+    """40 launches on the same operands (four waves with private DMA rings, counted waits, LDS reuse between the main loop and the
+    epilogue images, two tiles per workgroup: a race would show as a differing bit)."""
+    lib = _lib.load()
+    fmt, M, K, N = "fp16x3", 128 * 300, 768, 768
+    A, W, bias = _randn(M, K, seed=31), _randn(N, K, seed=32, scale=0.03), _randn(N, seed=33)
+    lw, lb, x0 = _randn(N, seed=34) + 1.0, _randn(N, seed=35), _randn(M, N, seed=36)
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    first = None
+    for it in range(40):
+        x = x0.clone()
+        out = torch.zeros((2, M, N), dtype=torch.float16, device=DEV)
+        _lib.check(lib.vtq_k_gemm_rowln(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, K, num_code(fmt), bias.data_ptr(), None, x.data_ptr(),
+                                        lw.data_ptr(), lb.data_ptr(), out.data_ptr(), M * N, stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (x, out)
+        else:
+            assert torch.equal(x, first[0]) and torch.equal(out.view(torch.int16), first[1].view(torch.int16)), it
+
+
 @pytest.mark.parametrize("fmt", ["bf16", "bf16x3", "fp16", "fp16x3"])
 @pytest.mark.parametrize("H", [768, 1024])
 def test_layernorm(fmt, H):

@@ -1035,6 +1035,18 @@ int vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64
     return 0;
 }
 
+int vtq_k_gemm_rowln(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t K, int32_t num,
+                     const float* bias, const float* gamma, float* x_f32, const float* ln_w, const float* ln_b, void* out16, int64_t o_plane,
+                     void* stream) {
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm) || nm.terms != 3) return fail("vtq_k_gemm_rowln: operand format code %d (3-term formats only)", num);
+    RowLnArgs a{};
+    a.A = A; a.a_plane = a_plane; a.lda = lda; a.W = W; a.w_plane = w_plane; a.M = M; a.N = 768; a.K = K; a.bias = bias; a.gamma = gamma;
+    a.x = x_f32; a.ln_w = ln_w; a.ln_b = ln_b; a.out = out16; a.o_plane = o_plane;
+    HIP_TRY(launch_gemm_rowln(a, nm, (hipStream_t)stream));
+    return 0;
+}
+
 int vtq_k_quant_rows_fp8(const float* W, void* dst, float* inv_scale, int32_t N, int32_t K, void* stream) {
     if (!W || !dst || !inv_scale || N < 1 || K < 4) return fail("vtq_k_quant_rows_fp8: bad argument");
     HIP_TRY(launch_quant_rows_fp8(W, dst, inv_scale, N, K, (hipStream_t)stream));

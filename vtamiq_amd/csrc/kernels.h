@@ -87,6 +87,18 @@ __host__ __device__ constexpr int gemm_flags(const GemmArgs&) { return 0; }
 #endif
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
+// Whole-row residual GEMM with LayerNorm in its epilogue (gemm_rowln.hip): x[M, 768] += gamma * (A W^T + bias), then (ln_w != NULL)
+// out planes = LayerNorm(x; ln_w, ln_b).  N = 768, 3-term operand formats, M % 128 == 0, K % 32 == 0.
+struct RowLnArgs {
+    const void* A; int64_t a_plane; int lda;      // activation planes [M, lda] (hi, lo)
+    const void* W; int64_t w_plane;               // weight planes [768, K]
+    int M, N, K;
+    const float* bias; const float* gamma;        // [768]; gamma NULL = 1
+    float* x;                                     // fp32 [M, 768], in / out
+    const float* ln_w; const float* ln_b;         // [768]; NULL: no LayerNorm output
+    void* out; int64_t o_plane;                   // planes [M, 768] of the normalised rows
+};
+hipError_t launch_gemm_rowln(const RowLnArgs& a, Num num, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
 bool attention_rule(int nseq, int S_pad, int H, int terms, int cus);   // host-only: would launch_attention pick the pipelined kernel?
 void attention_set_variant(int v);               // test / measurement hook: -1 default, 0 four-wave kernel, 1 ping-pong kernel

@@ -308,6 +308,7 @@ class VTAMIQ(nn.Module):
         with torch.cuda.device(self._engine_device):
             stream = torch.cuda.current_stream(self._engine_device).cuda_stream
             _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
+        flags.value |= self.__dict__.pop("_flags_seen", 0)       # bits the fp8 mode's own early look already collected (and cleared)
         if flags.value & 1:
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
         if flags.value & 4:
@@ -368,11 +369,10 @@ class VTAMIQ(nn.Module):
             if n < 3 or self.validate_inputs:
                 self.__dict__["_fp8_checked"] = n + 1
                 flags = self._read_flags()
+                self.__dict__["_flags_seen"] = self.__dict__.get("_flags_seen", 0) | flags      # check_inputs() still reports them
                 if flags & 4:
                     warnings.warn("[VTAMIQ] fp8 mode: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
                                   "activation scales do not fit this data; calibrate_fp8() on a representative batch")
-                if flags & 1:
-                    raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
         elif self.validate_inputs:
             self.check_inputs()
 
