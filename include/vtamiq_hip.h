@@ -73,7 +73,10 @@ typedef struct vtq_config {
  * VTQ_FP8_STATIC_SCALES is an explicit field of the configuration the caller hands over. */
 #define VTQ_OPT_FULL_LAST_LAYER   1   /* run the last encoder layer on every token row instead of on the CLS rows only (same result) */
 #define VTQ_OPT_FP8_STATIC_SCALES 2   /* VTQ_PREC_FP8: keep the static default activation scales, never calibrate                    */
-#define VTQ_OPT_SEPARATE_LAYERNORM 4  /* LayerNorm as its own launch in front of QKV / fc1 instead of inside the residual GEMMs     */
+#define VTQ_OPT_FUSED_LAYERNORM   4   /* LayerNorm inside the residual GEMMs: the out-proj launch also writes LayerNorm 2's operand planes, */
+                                      /* the fc2 launch the next layer's LayerNorm 1 planes (csrc/gemm_rowln.hip; hidden 768, 3-term          */
+                                      /* formats, no adapters: vtq_create fails otherwise).  Bit-identical scores; measured 1.3 % SLOWER at   */
+                                      /* B = 32 than separate LayerNorm launches, hence opt-in                               */
 
 typedef struct vtq_tensor_desc {
     const char*  name;         /* HOST string: the reference's state_dict key          */

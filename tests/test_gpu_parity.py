@@ -713,3 +713,39 @@ def test_rccl_single_rank_all_gather_of_the_scores():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "SAME 1 nccl" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("name,precision", [("c1_b2_n50", "fp16x3"), ("refdefault_b2_n64", "fp16x3"), ("unaligned_b3_n50", "bf16x3"), ("c2shape_b4_n500", "fp16x3"),
+                                            ("nocalib_b2_n30", "fp16x3"), ("stress5_b3_n90", "fp16x3")])
+def test_layernorm_inside_the_residual_gemms_is_bit_identical(name, precision):
+    """vtq_config.options & VTQ_OPT_FUSED_LAYERNORM (csrc/gemm_rowln.hip: the out-proj launch writes LayerNorm 2's planes, the fc2 launch
+    the next layer's LayerNorm 1 planes, 22 of the 23 LayerNorm launches of a ViT-B forward disappear): the same accumulation order and
+    the same LayerNorm arithmetic as the separate launches, so the SCORES are the same bits -- with registers, LayerScale, the CLS-pruned
+    and the full last layer, one layer (no LayerNorm behind its fc2), trained-like weights -- and every per-layer token row of the trace."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    B, L, T, H = int(g["B"]), spec.num_layers, spec.num_tokens, spec.hidden_size
+    with torch.no_grad():
+        q_sep = build(kw, sd, precision)(p, ps, sc)[0]
+        q_fused = build(kw, sd, precision, engine_options=_lib.OPT_FUSED_LAYERNORM)(p, ps, sc)[0]
+        q_full = build(kw, sd, precision, engine_options=_lib.OPT_FUSED_LAYERNORM | _lib.OPT_FULL_LAST_LAYER)(p, ps, sc)[0]
+        q_full_sep = build(kw, sd, precision, engine_options=_lib.OPT_FULL_LAST_LAYER)(p, ps, sc)[0]
+        ta, tb = torch.zeros(L + 1, 2 * B, T, H, device=DEV), torch.zeros(L + 1, 2 * B, T, H, device=DEV)
+        build(kw, sd, precision)(p, ps, sc, _trace=ta)
+        build(kw, sd, precision, engine_options=_lib.OPT_FUSED_LAYERNORM)(p, ps, sc, _trace=tb)
+    assert torch.equal(q_sep, q_fused) and torch.equal(q_full, q_full_sep)
+    assert torch.equal(ta, tb)
+    assert gate(q_fused.cpu().numpy(), g["q"], TOL[precision])
+
+
+def test_fused_layernorm_option_is_rejected_where_the_kernel_does_not_apply():
+    for kw, precision in ((dict(vit_config=dict(variant="ViT-L16", num_keep_layers=1, pretrained=False)), "fp16x3"),
+                          (dict(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False)), "fp16"),
+                          (dict(vit_config=dict(variant="ViT-B16", num_keep_layers=1, num_adapters=1, pretrained=False)), "fp16x3")):
+        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision, engine_options=_lib.OPT_FUSED_LAYERNORM).to(DEV).eval()
+        N = 16
+        p = torch.zeros(1, N, 3, 16, 16, device=DEV)
+        pos = torch.zeros(1, N, 2, device=DEV)
+        sc = (torch.zeros(1, N, device=DEV),) * 2 if m.spec.use_scale_embedding else (None, None)
+        with pytest.raises(RuntimeError, match="VTQ_OPT_FUSED_LAYERNORM"), torch.no_grad():
+            m((p, p), (pos, pos), sc)

@@ -8,10 +8,11 @@ from vtamiq_amd import VTAMIQ, synth, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--patches", type=int, default=500)
 ap.add_argument("--refdefault", action="store_true")
+ap.add_argument("--fused-ln", action="store_true", help="vtq_config.options & VTQ_OPT_FUSED_LAYERNORM: LayerNorm inside the residual GEMMs (csrc/gemm_rowln.hip)")
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16", "fp8"])
 a = ap.parse_args()
 for prec in a.precision:
-    m = VTAMIQ(precision=prec, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, pretrained=False),
+    m = VTAMIQ(precision=prec, engine_options=_lib.OPT_FUSED_LAYERNORM if a.fused_ln else 0, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, pretrained=False),
                                        ca_reduction=16) if a.refdefault else dict(vit_config=dict(variant="ViT-B16", pretrained=False))))
     sd = synth.make_state_dict(m.spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
@@ -28,7 +29,7 @@ for prec in a.precision:
         prof = m.profile_collect()
     ms = [prof[k][0] for k in _lib.KERNEL_CLASSES]; n = [prof[k][1] for k in _lib.KERNEL_CLASSES]
     tot = sum(ms) / a.steps
-    print(f"{prec} B={a.batch} N={a.patches}: {dt*1e3:.2f} ms/step unprofiled; classes sum {tot:.2f} ms")
+    print(f"{prec} B={a.batch} N={a.patches}{' LayerNorm inside the residual GEMMs' if a.fused_ln else ''}: {dt*1e3:.2f} ms/step unprofiled; classes sum {tot:.2f} ms")
     for k, name in enumerate(_lib.KERNEL_CLASSES):
         if n[k]:
             print(f"   {name:12s} {ms[k]/a.steps:7.3f} ms/step  {n[k]//a.steps:3d} launches  {ms[k]/n[k]*1e3:8.1f} us/launch")

@@ -23,7 +23,7 @@ MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3)
 ABI_VERSION = 5
 OPT_FULL_LAST_LAYER = 1
 OPT_FP8_STATIC_SCALES = 2
-OPT_SEPARATE_LAYERNORM = 4
+OPT_FUSED_LAYERNORM = 4
 
 KERNEL_CLASSES = ["convert", "patch_embed", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "head"]
 

@@ -135,6 +135,7 @@ struct vtq_engine {
     int64_t tl_plane = 0, th_plane = 0;
     float *xcls = nullptr, *lncls = nullptr, *qcls = nullptr;   // CLS-only last layer (fp32 rows)
     bool cls_prune = true;
+    bool fuse_ln = false;                // VTQ_OPT_FUSED_LAYERNORM: residual GEMMs carry the next LayerNorm in their epilogue (gemm_rowln.hip)
     int32_t* err_host = nullptr;         // pinned landing word of vtq_input_errors (a pageable destination goes through the runtime's staging path)
     int* err_flag = nullptr;             // device word (vtq_input_errors): bit 0 = a position outside [0, 1) was clamped, bit 1 = non-finite CLS difference
     std::vector<void*> ws_allocs;
@@ -458,12 +459,23 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
     char* big = (char*)e->big;                               // QKV (ld 3H) and the MLP hidden (ld M) alias: never live together
     float *xcls = e->xcls, *lncls = e->lncls, *qcls = e->qcls;
     const int64_t trace_stride = (int64_t)g.nseq * T * H;
+    // LayerNorm inside the residual GEMMs (gemm_rowln.hip): the out-proj launch also writes LayerNorm 2's planes, the fc2 launch the
+    // NEXT layer's LayerNorm 1 planes; only layer 0's LayerNorm 1 (behind the patch embedding) is a launch of its own.  Not while a
+    // test stops the encoder between stages (vtq_debug_stop_after addresses the separate stages).
+    const bool fused = e->fuse_ln && e->dbg_stop < 0;
+    auto resid_ln = [&](const void* A, int64_t a_plane, int lda, const void* W, int64_t w_plane, int K, const float* bias, const float* gamma,
+                        const float* lnw, const float* lnbias) -> hipError_t {
+        RowLnArgs a{};
+        a.A = A; a.a_plane = a_plane; a.lda = lda; a.W = W; a.w_plane = w_plane; a.M = M; a.N = H; a.K = K; a.bias = bias; a.gamma = gamma; a.x = x;
+        a.ln_w = lnw; a.ln_b = lnbias; a.out = lnb; a.o_plane = e->ln_plane;
+        return launch_gemm_rowln(a, lin, s);
+    };
     for (int i = 0; i < L; ++i) {
         const Layer& Ly = e->layers[i];
         if (prune && i == L - 1) {
             // ---- last layer: K/V for every row, everything else for the 2B CLS rows only (cls_tail.hip) ------------
             const int R = g.nseq;
-            { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
+            if (!(fused && i > 0)) { Prof p(e, s, VTQ_K_LN); HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, f16, apl, s)); }
             {
                 Prof p(e, s, VTQ_K_QKV);
                 GemmArgs a{};
@@ -528,7 +540,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
             return launch_gemm(u, lin, EPI_RESID, s);
         };
         const int lnf = f8m ? 2 : f16, lnp = f8m ? 1 : apl;
-        {
+        if (!(fused && i > 0)) {
             Prof p(e, s, VTQ_K_LN);
             if (f8m) {
                 if (fp8_stage(e, s, e->s_ln1[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_layernorm(x, Ly.ln1w, Ly.ln1b, lnb, e->ln_plane, M, H, 2, 1, s, sc, ob)); return 0; })) return 1;
@@ -563,11 +575,13 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
                 HIP_TRY(launch_gemm(hplanes, lin, EPI_BIAS, s));
             }
             a.gamma = Ly.g1; a.x = x;
+            if (fused) HIP_TRY(resid_ln(lnb, e->ln_plane, H, Ly.wo, Ly.po, H, Ly.bo, Ly.g1, Ly.ln2w, Ly.ln2b));   // x += ls1 * h; lnbuf = LayerNorm 2 (x)
+            else
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));              // x += ls1 * h
             if (adapters) HIP_TRY(adapter_site(Ly, 0, big, e->big_plane, lnb, e->ln_plane, Ly.g1));   // x += ls1 * (up(gelu(down(h))) )
         }
         if (e->dbg_stop == i * 7 + 3) return 0;
-        {
+        if (!fused) {
             Prof p(e, s, VTQ_K_LN);
             if (f8m) {
                 if (fp8_stage(e, s, e->s_ln2[i], [&](float sc, Fp8Obs ob) { HIP_TRY(launch_layernorm(x, Ly.ln2w, Ly.ln2b, lnb, e->ln_plane, M, H, 2, 1, s, sc, ob)); return 0; })) return 1;
@@ -597,6 +611,10 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
                 HIP_TRY(launch_gemm(hplanes, lin, EPI_BIAS, s));
             }
             a.gamma = Ly.g2; a.x = x;
+            if (fused) {                         // x += ls2 * h; lnbuf = the next layer's LayerNorm 1 (x) (none behind the last layer: final_diff normalises the CLS rows)
+                const Layer* nx = (i + 1 < L) ? &e->layers[i + 1] : nullptr;
+                HIP_TRY(resid_ln(big, e->big_plane, Md, Ly.w2, Ly.p2, Md, Ly.b2, Ly.g2, nx ? nx->ln1w : nullptr, nx ? nx->ln1b : nullptr));
+            } else
             HIP_TRY(launch_gemm(a, lin, EPI_RESID, s));
             if (adapters) HIP_TRY(adapter_site(Ly, 1, lnb, e->ln_plane, big, e->big_plane, Ly.g2));
         }
@@ -723,6 +741,11 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     e->Mdim = c.mlp_dim;
     e->T = 1 + c.num_extra_tokens;
     e->cls_prune = !(c.options & VTQ_OPT_FULL_LAST_LAYER);
+    e->fuse_ln = (c.options & VTQ_OPT_FUSED_LAYERNORM) != 0;
+    if (e->fuse_ln && !(c.hidden_size == 768 && !e->fp8 && e->lin.terms == 3 && c.num_adapters == 0)) {
+        delete e;
+        return fail("VTQ_OPT_FUSED_LAYERNORM needs hidden_size 768, a 3-term precision (fp16x3 / bf16x3) and no adapters");
+    }
     e->s_ln1.assign(c.num_layers, kSLn); e->s_att.assign(c.num_layers, kSAtt); e->s_ln2.assign(c.num_layers, kSLn); e->s_gelu.assign(c.num_layers, kSGelu);
     e->fp8_static = (c.options & VTQ_OPT_FP8_STATIC_SCALES) != 0;
     if (hipMalloc((void**)&e->err_flag, 16) != hipSuccess || hipMemset(e->err_flag, 0, 16) != hipSuccess) {

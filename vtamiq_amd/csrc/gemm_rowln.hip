@@ -70,22 +70,38 @@ __device__ __forceinline__ void wait_vm_rt(int n) {
 // therefore ends with the wait states a 4-pass MFMA needs before any reader or writer of its result (cdna_hip_programming.md 5.7 item 2),
 // and every statement opens with the two states between a VALU / v_accvgpr_write of an operand (the lazily placed bias initialisation of
 // the accumulators) and the MFMA reading it.  Both ride in the previous MFMA's 16 cycles.
+#ifndef VTQ_RL_PRE
+#define VTQ_RL_PRE "s_nop 1\n\t"       // measurement builds may empty these two (wrong results possible)
+#endif
+#ifndef VTQ_RL_POST
+#define VTQ_RL_POST "\n\ts_nop 7"
+#endif
+#define VTQ_RL_MM3(TY) "v_mfma_f32_16x16x32_" TY " %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_" TY " %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_" TY " %0, %2, %3, %0"
+// two row blocks at once, their chains interleaved (each accumulator still sees hi*hi, hi*lo, lo*hi in that order):
+// %0 %1 = accumulators, %2 %3 = w_hi w_lo, %4 %5 = a_hi a_lo of the first row block, %6 %7 of the second
+#define VTQ_RL_MM6(TY)                                                                                             \
+    "v_mfma_f32_16x16x32_" TY " %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_" TY " %1, %2, %6, %1\n\t"                   \
+    "v_mfma_f32_16x16x32_" TY " %0, %2, %5, %0\n\tv_mfma_f32_16x16x32_" TY " %1, %2, %7, %1\n\t"                   \
+    "v_mfma_f32_16x16x32_" TY " %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_" TY " %1, %3, %6, %1"
 template <typename T, bool AG>
 __device__ __forceinline__ void mma3(f32x4& c, const u32x4& w_hi, const u32x4& w_lo, const u32x4& a_hi, const u32x4& a_lo) {
     if constexpr (std::is_same<T, f16>::value) {
-        if constexpr (AG)
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
-                         : "+a"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
-        else
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\ts_nop 7"
-                         : "+v"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
+        if constexpr (AG) asm volatile(VTQ_RL_PRE VTQ_RL_MM3("f16") : "+a"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
+        else asm volatile(VTQ_RL_PRE VTQ_RL_MM3("f16") VTQ_RL_POST : "+v"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
     } else {
-        if constexpr (AG)
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
-                         : "+a"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
-        else
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\ts_nop 7"
-                         : "+v"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
+        if constexpr (AG) asm volatile(VTQ_RL_PRE VTQ_RL_MM3("bf16") : "+a"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
+        else asm volatile(VTQ_RL_PRE VTQ_RL_MM3("bf16") VTQ_RL_POST : "+v"(c) : "v"(w_hi), "v"(w_lo), "v"(a_hi), "v"(a_lo));
+    }
+}
+template <typename T, bool AG>
+__device__ __forceinline__ void mma6(f32x4& c0, f32x4& c1, const u32x4& w_hi, const u32x4& w_lo, const u32x4& a0_hi, const u32x4& a0_lo,
+                                     const u32x4& a1_hi, const u32x4& a1_lo) {
+    if constexpr (std::is_same<T, f16>::value) {
+        if constexpr (AG) asm volatile(VTQ_RL_PRE VTQ_RL_MM6("f16") : "+a"(c0), "+a"(c1) : "v"(w_hi), "v"(w_lo), "v"(a0_hi), "v"(a0_lo), "v"(a1_hi), "v"(a1_lo));
+        else asm volatile(VTQ_RL_PRE VTQ_RL_MM6("f16") VTQ_RL_POST : "+v"(c0), "+v"(c1) : "v"(w_hi), "v"(w_lo), "v"(a0_hi), "v"(a0_lo), "v"(a1_hi), "v"(a1_lo));
+    } else {
+        if constexpr (AG) asm volatile(VTQ_RL_PRE VTQ_RL_MM6("bf16") : "+a"(c0), "+a"(c1) : "v"(w_hi), "v"(w_lo), "v"(a0_hi), "v"(a0_lo), "v"(a1_hi), "v"(a1_lo));
+        else asm volatile(VTQ_RL_PRE VTQ_RL_MM6("bf16") VTQ_RL_POST : "+v"(c0), "+v"(c1) : "v"(w_hi), "v"(w_lo), "v"(a0_hi), "v"(a0_lo), "v"(a1_hi), "v"(a1_lo));
     }
 }
 
@@ -106,6 +122,7 @@ struct RowLnKArgs {
     float* x;
     const float* ln_w; const float* ln_b;
     void* out; int64_t o_plane;
+    unsigned long long* diag;                     // -DVTQ_GEMM_DIAG builds: gemm_diag_buffer(); never read otherwise
 };
 
 enum { KT_FIRST = 0, KT_MID = 1, KT_PENULT = 2, KT_LAST = 3 };     // position of a K tile in its row tile (nkt >= 4)
@@ -121,8 +138,23 @@ __global__ __launch_bounds__(256, 1) void gemm_rowln_kernel(RowLnKArgs p) {
     f32x4 acc[8][kCb];                               // [row block][column block]; column blocks 0..7 in AGPRs, 8..11 in VGPRs
     u32x4 ah[8], al[8], wh[2], wl[2];
 
+#ifdef VTQ_GEMM_DIAG
+    // diagnostic build only: shader-clock / 100 MHz stamps per phase, summed over this workgroup's tiles, into a buffer nothing else reads
+    unsigned long long dg_c[4] = {0, 0, 0, 0}, dg_r[4] = {0, 0, 0, 0}, dg_t, dg_rt, dg_aw = 0, dg_ww = 0;
+    auto tick = [&]() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
+    auto stamp = [&](int k) {
+        unsigned long long t, r;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) :: "memory");
+        if (k >= 0) { dg_c[k] += t - dg_t; dg_r[k] += r - dg_rt; }
+        dg_t = t; dg_rt = r;
+    };
+#define VTQ_RL_STAMP(k) stamp(k);
+#else
+#define VTQ_RL_STAMP(k)
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t m0 = (int64_t)tile * kRows;
+        VTQ_RL_STAMP(-1)
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));               // per-lane addressing is re-derived here for every tile (nothing lives across the epilogue)
         const int fr = lane & 15, fq = lane >> 4;
@@ -197,10 +229,11 @@ __global__ __launch_bounds__(256, 1) void gemm_rowln_kernel(RowLnKArgs p) {
 
         // One column-block step = 24 MFMAs (8 row blocks x 3 terms) = 384 matrix-pipe cycles, issued by ONE wave per SIMD: everything else
         // of the step rides between the MFMA groups (a clustered LDS-DMA issue of ~60 cycles each would idle the pipe):
-        //   after group 0: refill request, hi plane      after group 2: refill request, lo plane
-        //   after group 4: wait for block g + 1, read its fragment (needed at the top of the next step)
-        //   last step of a K tile: A(kt + 1) is waited for + barrier at its top; the A fragments of row block i - 1 are reloaded after
-        //   group i; the four pieces of A(kt + 2) are requested after groups 1, 3, 5, 6.
+        // the MFMAs go out as four statements of two row blocks each (six MFMAs, the two accumulation chains interleaved); behind
+        //   statement 0: refill request, hi plane      statement 1: refill request, lo plane
+        //   statement 2: wait for block g + 1, read its fragment (needed at the top of the next step)
+        //   last step of a K tile: A(kt + 1) is waited for + barrier at its top; the A fragments of the row blocks one statement back are
+        //   reloaded behind statements 1, 2, 3 (the last two blocks behind the step); one piece of A(kt + 2) is requested behind each.
         auto ktile = [&](int kt, auto pos_c) {
             constexpr int POS = decltype(pos_c)::value;
 #pragma unroll
@@ -213,8 +246,14 @@ __global__ __launch_bounds__(256, 1) void gemm_rowln_kernel(RowLnKArgs p) {
                     // A(kt + 1) landed for everyone; everyone has long finished reading A(kt) into registers -> its slot takes A(kt + 2).
                     // Younger than A(kt + 1)'s last piece: the refills of 11 steps (8 at the penultimate K tile; 16 + 11 W pairs behind the
                     // prologue's A(1))
+#ifdef VTQ_GEMM_DIAG
+                    const unsigned long long ta = tick();
+#endif
                     if (POS == KT_FIRST) wait_vm<54>(); else if (POS == KT_MID) wait_vm<22>(); else wait_vm<16>();
                     __builtin_amdgcn_s_barrier();
+#ifdef VTQ_GEMM_DIAG
+                    dg_aw += tick() - ta;            // cycles in the wait for A(kt + 1) + the K tile's barrier
+#endif
                 }
                 // W fragment of block j (and, at j = 0, the A fragments reloaded during the previous step) have arrived; the statement
                 // names them so that no compiler copy of these registers can sit between the reads and the wait
@@ -224,40 +263,70 @@ __global__ __launch_bounds__(256, 1) void gemm_rowln_kernel(RowLnKArgs p) {
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[j & 1]), "+v"(wl[j & 1]) :: "memory");
                 const int kt_n = kt + 1 + (j + 4 >= kCb ? 1 : 0), j_n = (j + 4) % kCb;       // block g + 16: its slot (g % 16) is free now
                 const uint32_t an = a_rd + (uint32_t)(((kt + 1) & 1) * kASlot);
+#ifndef VTQ_RL_MM
+#define VTQ_RL_MM 1                   // 1: two row blocks per MFMA statement, chains interleaved; 0: one row block (three dependent MFMAs back to back)
+#endif
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+#if VTQ_RL_MM == 1
+                    if ((i & 1) == 0) {
+                        if (j < 8) mma6<T, true>(acc[i][j], acc[i + 1][j], wh[j & 1], wl[j & 1], ah[i], al[i], ah[i + 1], al[i + 1]);
+                        else mma6<T, false>(acc[i][j], acc[i + 1][j], wh[j & 1], wl[j & 1], ah[i], al[i], ah[i + 1], al[i + 1]);
+                        continue;
+                    }
+#else
                     if (j < 8) mma3<T, true>(acc[i][j], wh[j & 1], wl[j & 1], ah[i], al[i]);
                     else mma3<T, false>(acc[i][j], wh[j & 1], wl[j & 1], ah[i], al[i]);
-                    if (i == 0 && refill) stage_w(kt_n, j_n, 0);
-                    if (i == 2 && refill) stage_w(kt_n, j_n, 1);
-                    if (i == 4 && r > 1) {
+#endif
+                    // fillers behind the MFMAs of row blocks (i - 1, i) [pair form: i odd] / of row block i
+#if !(defined(VTQ_RL_ABL) && (VTQ_RL_ABL & 1))              // measurement build bit 0: no W refills in the K loop (results wrong by design)
+                    if (i == 1 && refill) stage_w(kt_n, j_n, 0);
+                    if (i == 3 && refill) stage_w(kt_n, j_n, 1);
+#endif
+                    if (i == 5 && r > 1) {
                         // W block g + 1 landed: 15 W pairs are younger in the steady state (r - 2 in the last 16 steps); A pieces among
                         // them are waited for as well
+#if defined(VTQ_RL_ABL) && (VTQ_RL_ABL & 1)
+                        if (false) {}
+#else
+#ifdef VTQ_GEMM_DIAG
+                        if (r > kRing) { const unsigned long long tw = tick(); wait_vm<30>(); dg_ww += tick() - tw; }      // cycles in the wait for W(g + 1)
+#else
                         if (r > kRing) wait_vm<30>();
+#endif
+#endif
                         else if (r == 16) wait_vm<28>(); else if (r == 15) wait_vm<26>(); else if (r == 14) wait_vm<24>(); else if (r == 13) wait_vm<22>();
                         else if (r == 12) wait_vm<20>(); else if (r == 11) wait_vm<18>(); else if (r == 10) wait_vm<16>(); else if (r == 9) wait_vm<14>();
                         else if (r == 8) wait_vm<12>(); else if (r == 7) wait_vm<10>(); else if (r == 6) wait_vm<8>(); else if (r == 5) wait_vm<6>();
                         else if (r == 4) wait_vm<4>(); else if (r == 3) wait_vm<2>(); else wait_vm<0>();
+#if !(defined(VTQ_RL_ABL) && (VTQ_RL_ABL & 2))              // measurement build bit 1: no W fragment reads
                         const uint32_t wa = w_rd + (uint32_t)(((g + 1) & (kRing - 1)) * kWSlot);
                         lds_rd<0>(wh[(j + 1) & 1], wa);
                         lds_rd<1024>(wl[(j + 1) & 1], wa);
+#endif
                     }
                     if (last_step) {
-                        if (i >= 1) read_a(i - 1, an);          // row block i - 1's fragments are dead: reload them from A(kt + 1), one group behind
+                        // the fragments of the row blocks one filler slot behind are dead: reload them from A(kt + 1)
+                        if (i == 3) { read_a(0, an); read_a(1, an); }
+                        if (i == 5) { read_a(2, an); read_a(3, an); }
+                        if (i == 7) { read_a(4, an); read_a(5, an); }
                         if (POS != KT_PENULT) {
-                            if (i == 1) stage_a(kt + 2, 0); else if (i == 3) stage_a(kt + 2, 1); else if (i == 5) stage_a(kt + 2, 2); else if (i == 6) stage_a(kt + 2, 3);
+                            if (i == 1) stage_a(kt + 2, 0); else if (i == 3) stage_a(kt + 2, 1); else if (i == 5) stage_a(kt + 2, 2); else if (i == 7) stage_a(kt + 2, 3);
                         }
                     }
                 }
+                if (last_step) { read_a(6, an); }
                 if (last_step) read_a(7, an);
             }
         };
+        VTQ_RL_STAMP(0)                              // [0] prologue: bias, first requests, A(0) / W(0) landed
         ktile(0, std::integral_constant<int, KT_FIRST>());
         for (int kt = 1; kt < nkt - 2; ++kt) ktile(kt, std::integral_constant<int, KT_MID>());
         ktile(nkt - 2, std::integral_constant<int, KT_PENULT>());
         ktile(nkt - 1, std::integral_constant<int, KT_LAST>());
         // ---- epilogue ------------------------------------------------------------------------------------------------------------------
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMA's result before any reader of the accumulators
+        VTQ_RL_STAMP(1)                                         // [1] the K loop
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();                           // every wave is done with the rings: the LDS is the epilogue's now
         // LDS now: two fp32 images of 16 rows (accumulators of a pass, row pitch 3088 B) | the residual rows of a pass (16 x 3072 B, filled
@@ -383,10 +452,20 @@ __global__ __launch_bounds__(256, 1) void gemm_rowln_kernel(RowLnKArgs p) {
                 __builtin_amdgcn_s_barrier();                    // ... everyone's are, and everyone has read image pass
             }
         }
+        VTQ_RL_STAMP(2)                                         // [2] the epilogue up to its last store's issue
         wait_vm<0>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                           // the images are dead before the next tile's DMA lands on them
+        VTQ_RL_STAMP(3)                                         // [3] the drain of the stores
     }
+#ifdef VTQ_GEMM_DIAG
+    if (p.diag && threadIdx.x == 0) {
+        unsigned long long* d = p.diag + (size_t)blockIdx.x * 64;
+        for (int k = 0; k < 4; ++k) { d[k] = dg_c[k]; d[4 + k] = dg_r[k]; }
+        d[8] = dg_aw; d[9] = dg_ww;
+    }
+#endif
+#undef VTQ_RL_STAMP
 }
 
 }  // namespace
@@ -415,7 +494,7 @@ hipError_t launch_gemm_rowln(const RowLnArgs& a, Num num, hipStream_t s) {
             done = true;
         }
     }
-    RowLnKArgs k{a.A, a.a_plane, a.lda, a.W, a.w_plane, a.M, a.K, a.bias, a.gamma, a.x, a.ln_w, a.ln_b, a.out, a.o_plane};
+    RowLnKArgs k{a.A, a.a_plane, a.lda, a.W, a.w_plane, a.M, a.K, a.bias, a.gamma, a.x, a.ln_w, a.ln_b, a.out, a.o_plane, gemm_diag_buffer()};
     const int ntiles = a.M / kRows;
     const int grid = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, s, k);
