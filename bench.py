@@ -165,6 +165,90 @@ def mode_fidelity(torch, make_model, spec, sd_np, modes, device, pairs=64, N=500
     return out
 
 
+def e2e_validation(torch, model, B, N, device, batches=40, warmup=3, H=384, W=512, seed=99):
+    """End-to-end throughput from the dataloader boundary (train.py:583-644, data/patch_sampling.py:529-611): a
+    validation loop fed with HOST uint8 images and host-sampled patch coordinates.  Per batch: pinned host buffers -> H2D on a copy
+    stream -> vtamiq_amd.patches.extract_patches (normalise + gather on the GPU) -> the model's forward; the scores stay on the GPU and
+    the loop ends with vtamiq_amd.validate's reductions (ranks / Kendall / Pearson kernels + the host's logistic fit).  Two buffer sets:
+    the copy of batch i + 1 runs under the forward of batch i.  Returns pairs/s over `batches` batches incl. the final reductions."""
+    import numpy as np
+    import scipy.optimize                                    # noqa: F401  (validate's logistic fit: imported at start-up, as a validation process would)
+    from vtamiq_amd.patches import check_samples_host, extract_patches
+    from vtamiq_amd.validate import compute_correlations_cat_flat
+    NI = 2 * B
+    rs = np.random.RandomState(seed)
+    nbuf = 2
+    host_img = [torch.from_numpy(rs.randint(0, 256, size=(NI, H, W, 3), dtype=np.uint8)).pin_memory() for _ in range(nbuf)]
+    host_smp = [torch.empty(NI, N, 2, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
+    dev_img = [torch.empty(NI, H, W, 3, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+    dev_smp = [torch.empty(NI, N, 2, dtype=torch.int32, device=device) for _ in range(nbuf)]
+    noise = torch.from_numpy(rs.randn(batches * B).astype(np.float32)).to(device)
+    copy_stream = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    copied = [torch.cuda.Event() for _ in range(nbuf)]
+    consumed = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def sample(i):                                           # the CPU sampler's part (coordinates only; aligned: ref and dist share them)
+        s = i % nbuf
+        consumed[s].synchronize()                            # the pinned buffers of this slot are no longer being copied from
+        smp = host_smp[s].numpy()
+        half = np.stack([rs.randint(0, H - 15, size=(B, N)), rs.randint(0, W - 15, size=(B, N))], axis=-1).astype(np.int32)
+        smp[:B], smp[B:] = half, half
+        check_samples_host(host_smp[s], None, H, W)
+
+    def upload(i):
+        s = i % nbuf
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[s])              # the device buffers of this slot were read by batch i - 2
+            dev_img[s].copy_(host_img[s], non_blocking=True)
+            dev_smp[s].copy_(host_smp[s], non_blocking=True)
+            copied[s].record(copy_stream)
+
+    def score(i):
+        s = i % nbuf
+        main.wait_event(copied[s])
+        patches, pos, _ = extract_patches(dev_img[s], dev_smp[s], validate=False)
+        consumed[s].record(main)                             # after the gather: the uint8 images and samples are free again
+        q = model((patches[:B], patches[B:]), (pos[:B], pos[B:]), (None, None))[0]
+        return q
+
+    for ev in consumed:
+        ev.record(main)
+    # first use of the reduction kernels and of scipy's fit (code-object load, imports): not part of a steady-state validation pass
+    compute_correlations_cat_flat([torch.linspace(0, 1, 64, device=device)], [torch.linspace(0, 1, 64, device=device) ** 2 + 0.01 * noise[:64]])
+    total = batches + warmup
+    ys, yps = [], []
+    with torch.no_grad():
+        sample(0); upload(0)
+        t0 = None
+        for i in range(total):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            if i + 1 < total:
+                sample(i + 1); upload(i + 1)                # under batch i's forward
+            q = score(i)
+            if i >= warmup:
+                yps.append(q)
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter() - t0
+        # the set's MOS values: synthetic, correlated with the scores as a trained model's are (SROCC ~ 0.9), so that the logistic fit
+        # behind PLCC / RMSE converges as it does on real data (built on the device, outside nothing: it is part of the timed region)
+        qa = torch.cat(yps)
+        ys = [(qa - qa.mean()) / qa.std() + 0.45 * noise]
+        corr = compute_correlations_cat_flat(ys, [qa])       # device reductions + the one D2H copy + the host's logistic fit: once per validation set
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    bytes_pair = (2 * H * W * 3 + 2 * N * 2 * 4)
+    return {"value": batches * B / dt, "unit": "image-pairs/s", "batches": batches, "batch": B, "patches": N, "seconds": dt,
+            "ms_per_batch": t_loop / batches * 1e3, "loop_seconds": t_loop, "reductions_seconds": dt - t_loop,
+            "value_loop_only": batches * B / t_loop, "image_hw": [H, W], "pcie_bytes_per_pair": bytes_pair,
+            "pcie_gbps_at_this_rate": bytes_pair * batches * B / dt / 1e9,
+            "pipeline": "pinned host uint8 images + host-sampled coordinates -> H2D on a copy stream (two buffer sets) -> extract_patches "
+                        "(normalise + gather) -> forward -> scores kept on the GPU -> validate.compute_correlations_cat_flat at the end",
+            "SROCC_of_the_synthetic_targets": corr["SROCC"]}
+
+
 def fc1_traffic(precision, B):
     """HBM bytes of ONE full-batch fc1 GEMM from the committed PMC passes (profiles/*_gemm_fc1_traffic.json: FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs at B=32), scaled linearly with the batch.  A committed
@@ -329,6 +413,7 @@ def main():
                     help="--gpus 1: put the world-size-1 RCCL all-gather of the scores INTO the timed step as well (default: it is "
                          "executed and timed in its own block, `collective`)")
     ap.add_argument("--no-collective-check", action="store_true", help="--gpus 1: skip the world-size-1 RCCL block")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e` block (validation loop from host uint8 images)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reference-default-topology row (`secondary`)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are stopped")
     # launcher self-test on CPU (tests/test_bench_launcher.py): gloo ranks + a stub model, no HIP anywhere
@@ -626,6 +711,14 @@ def main():
             del m
             torch.cuda.empty_cache()
         out["north_star_point"] = ns
+    if not a.no_e2e and world == 1 and on_gpu:
+        me = make_model(a.precision)
+        out["e2e"] = e2e_validation(torch, me, B, N, device)
+        out["e2e"]["frac_of_value"] = out["e2e"]["value"] / pairs_per_s
+        out["e2e"]["loop_frac_of_value"] = out["e2e"]["value_loop_only"] / pairs_per_s
+        out["e2e"]["numerics"] = a.precision
+        del me
+        torch.cuda.empty_cache()
     if not a.no_secondary and world == 1 and on_gpu:
         # SURVEY 8(d) secondary row: the reference-default topology -- what the released checkpoint runs (train_config.py:169-194,
         # 356-369: 6 kept layers, 8 register tokens, LayerScale, ca_reduction 16) at B = 16, N = 512

@@ -11,13 +11,42 @@ import torch
 from . import _lib
 
 
+def check_samples_host(samples: torch.Tensor, scale_ids: Optional[torch.Tensor], H: int, W: int, num_scales: int = 1, patch_size: int = 16) -> None:
+    """The range check of the sampled coordinates (IndexError like the reference's numpy fancy-indexing).  Works on the tensors where they
+    are: host tensors cost no GPU synchronisation (a pipelined loader calls this BEFORE the copy and passes validate=False below)."""
+    P = int(patch_size)
+    if samples.device.type == "cpu" and (scale_ids is None or scale_ids.device.type == "cpu"):
+        # numpy on the calling thread: torch CPU operators on these small tensors wake the intra-op thread pool, whose spinning workers
+        # then compete with the HIP runtime's own threads -- measured: a pipelined loop fell from 15.4 to 31 ms per batch with the
+        # torch form of this check on the host (tools/e2e_probe.py)
+        import numpy as np
+        smp_np = samples.detach().numpy()
+        lvl_np = scale_ids.detach().numpy().astype(np.int64) if scale_ids is not None else np.zeros(smp_np.shape[:2], dtype=np.int64)
+        if ((lvl_np < 0) | (lvl_np >= num_scales)).any():
+            raise IndexError("scale_ids outside [0, num_scales)")
+        hmax_np = np.array([(H >> s) - P for s in range(num_scales)])[lvl_np]
+        wmax_np = np.array([(W >> s) - P for s in range(num_scales)])[lvl_np]
+        if ((smp_np[..., 0] < 0) | (smp_np[..., 0] > hmax_np) | (smp_np[..., 1] < 0) | (smp_np[..., 1] > wmax_np)).any():
+            raise IndexError(f"patch sample outside its pyramid level (row in [0, h-{P}], col in [0, w-{P}] required)")
+        return
+    smp = samples.to(torch.int64)
+    lvl = scale_ids.to(device=smp.device, dtype=torch.int64) if scale_ids is not None else torch.zeros(smp.shape[:2], dtype=torch.int64, device=smp.device)
+    if bool(((lvl < 0) | (lvl >= num_scales)).any()):
+        raise IndexError("scale_ids outside [0, num_scales)")
+    hmax = torch.tensor([(H >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
+    wmax = torch.tensor([(W >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
+    if bool(((smp[..., 0] < 0) | (smp[..., 0] > hmax) | (smp[..., 1] < 0) | (smp[..., 1] > wmax)).any()):
+        raise IndexError(f"patch sample outside its pyramid level (row in [0, h-{P}], col in [0, w-{P}] required)")
+
+
 def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: Optional[torch.Tensor] = None, num_scales: int = 1,
                     flips: Optional[torch.Tensor] = None, mean: Sequence[float] = (0.5, 0.5, 0.5), std: Sequence[float] = (0.5, 0.5, 0.5),
-                    patch_size: int = 16) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+                    patch_size: int = 16, validate: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """images_u8 [NI, H, W, 3] uint8 (cuda); samples [NI, N, 2] int32 (row, col at the patch's own scale);
     scale_ids [NI, N] int32 (required when num_scales > 1, patches of scale s index pyramid level s); flips [NI, 2] int32
     (hflip, vflip) or None; patch_size P = 16 (ViT-B16 / ViT-L16) or 8 (ViT-B8).  Returns patches [NI, N, 3, P, P] f32, pos [NI, N, 2] f32,
-    scales [NI, N] f32 or None."""
+    scales [NI, N] f32 or None.  validate=False skips the device-side range check of the samples (one reduction + a stream
+    synchronisation): for a pipelined loader that has checked them on the host before the copy (check_samples_host)."""
     lib = _lib.load()
     dev = images_u8.device
     if dev.type != "cuda":
@@ -39,16 +68,10 @@ def extract_patches(images_u8: torch.Tensor, samples: torch.Tensor, scale_ids: O
     # gather kernel itself does not bounds-check.  One small reduction + sync per call, on the loader side of the pipeline.
     if (H >> (num_scales - 1)) < P or (W >> (num_scales - 1)) < P:
         raise ValueError(f"pyramid level {num_scales - 1} of a {H}x{W} image is smaller than one {P}x{P} patch")
-    smp = samples.to(torch.int64)
-    lvl = scale_ids.to(device=smp.device, dtype=torch.int64) if scale_ids is not None else torch.zeros(smp.shape[:2], dtype=torch.int64, device=smp.device)
-    if tuple(lvl.shape) != (NI, N):
+    if scale_ids is not None and tuple(scale_ids.shape) != (NI, N):
         raise ValueError("scale_ids must be int32 [NI, N]")
-    if bool(((lvl < 0) | (lvl >= num_scales)).any()):
-        raise IndexError("scale_ids outside [0, num_scales)")
-    hmax = torch.tensor([(H >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
-    wmax = torch.tensor([(W >> s) - P for s in range(num_scales)], device=smp.device)[lvl]
-    if bool(((smp[..., 0] < 0) | (smp[..., 0] > hmax) | (smp[..., 1] < 0) | (smp[..., 1] > wmax)).any()):
-        raise IndexError(f"patch sample outside its pyramid level (row in [0, h-{P}], col in [0, w-{P}] required)")
+    if validate:
+        check_samples_host(samples, scale_ids, H, W, num_scales, P)
     images_u8 = images_u8.contiguous()
     samples = samples.to(device=dev, dtype=torch.int32).contiguous()
     sid = scale_ids.to(device=dev, dtype=torch.int32).contiguous() if scale_ids is not None else None
