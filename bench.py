@@ -173,67 +173,34 @@ def e2e_validation(torch, model, B, N, device, batches=40, warmup=3, H=384, W=51
     the copy of batch i + 1 runs under the forward of batch i.  Returns pairs/s over `batches` batches incl. the final reductions."""
     import numpy as np
     import scipy.optimize                                    # noqa: F401  (validate's logistic fit: imported at start-up, as a validation process would)
-    from vtamiq_amd.patches import check_samples_host, extract_patches
+    from vtamiq_amd.pipeline import ImagePairPipeline
     from vtamiq_amd.validate import compute_correlations_cat_flat
     NI = 2 * B
     rs = np.random.RandomState(seed)
-    nbuf = 2
-    host_img = [torch.from_numpy(rs.randint(0, 256, size=(NI, H, W, 3), dtype=np.uint8)).pin_memory() for _ in range(nbuf)]
-    host_smp = [torch.empty(NI, N, 2, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
-    dev_img = [torch.empty(NI, H, W, 3, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-    dev_smp = [torch.empty(NI, N, 2, dtype=torch.int32, device=device) for _ in range(nbuf)]
+    pipe = ImagePairPipeline(model, B, (H, W), N, device=device)          # pinned host buffers, copy stream, two buffer sets
+    pool = [rs.randint(0, 256, size=(NI, H, W, 3), dtype=np.uint8) for _ in range(2)]        # the "decoded images" of the synthetic set
     noise = torch.from_numpy(rs.randn(batches * B).astype(np.float32)).to(device)
-    copy_stream = torch.cuda.Stream(device=device)
-    main = torch.cuda.current_stream(device)
-    copied = [torch.cuda.Event() for _ in range(nbuf)]
-    consumed = [torch.cuda.Event() for _ in range(nbuf)]
-
-    def sample(i):                                           # the CPU sampler's part (coordinates only; aligned: ref and dist share them)
-        s = i % nbuf
-        consumed[s].synchronize()                            # the pinned buffers of this slot are no longer being copied from
-        smp = host_smp[s].numpy()
-        half = np.stack([rs.randint(0, H - 15, size=(B, N)), rs.randint(0, W - 15, size=(B, N))], axis=-1).astype(np.int32)
-        smp[:B], smp[B:] = half, half
-        check_samples_host(host_smp[s], None, H, W)
-
-    def upload(i):
-        s = i % nbuf
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(consumed[s])              # the device buffers of this slot were read by batch i - 2
-            dev_img[s].copy_(host_img[s], non_blocking=True)
-            dev_smp[s].copy_(host_smp[s], non_blocking=True)
-            copied[s].record(copy_stream)
-
-    def score(i):
-        s = i % nbuf
-        main.wait_event(copied[s])
-        patches, pos, _ = extract_patches(dev_img[s], dev_smp[s], validate=False)
-        consumed[s].record(main)                             # after the gather: the uint8 images and samples are free again
-        q = model((patches[:B], patches[B:]), (pos[:B], pos[B:]), (None, None))[0]
-        return q
-
-    for ev in consumed:
-        ev.record(main)
     # first use of the reduction kernels and of scipy's fit (code-object load, imports): not part of a steady-state validation pass
     compute_correlations_cat_flat([torch.linspace(0, 1, 64, device=device)], [torch.linspace(0, 1, 64, device=device) ** 2 + 0.01 * noise[:64]])
     total = batches + warmup
-    ys, yps = [], []
+    yps = []
     with torch.no_grad():
-        sample(0); upload(0)
         t0 = None
         for i in range(total):
             if i == warmup:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            if i + 1 < total:
-                sample(i + 1); upload(i + 1)                # under batch i's forward
-            q = score(i)
+            img, smp, _ = pipe.acquire()                    # the loader's part: "decode" into the pinned slot, sample the coordinates (aligned pairs)
+            img[:] = pool[i % 2]
+            half = np.stack([rs.randint(0, H - 15, size=(B, N)), rs.randint(0, W - 15, size=(B, N))], axis=-1).astype(np.int32)
+            smp[:B], smp[B:] = half, half
+            q = pipe.launch()                               # range check, H2D on the copy stream, gather + forward: all enqueued
             if i >= warmup:
                 yps.append(q)
         torch.cuda.synchronize()
         t_loop = time.perf_counter() - t0
         # the set's MOS values: synthetic, correlated with the scores as a trained model's are (SROCC ~ 0.9), so that the logistic fit
-        # behind PLCC / RMSE converges as it does on real data (built on the device, outside nothing: it is part of the timed region)
+        # behind PLCC / RMSE converges as it does on real data (built on the device, inside the timed region)
         qa = torch.cat(yps)
         ys = [(qa - qa.mean()) / qa.std() + 0.45 * noise]
         corr = compute_correlations_cat_flat(ys, [qa])       # device reductions + the one D2H copy + the host's logistic fit: once per validation set
@@ -244,8 +211,9 @@ def e2e_validation(torch, model, B, N, device, batches=40, warmup=3, H=384, W=51
             "ms_per_batch": t_loop / batches * 1e3, "loop_seconds": t_loop, "reductions_seconds": dt - t_loop,
             "value_loop_only": batches * B / t_loop, "image_hw": [H, W], "pcie_bytes_per_pair": bytes_pair,
             "pcie_gbps_at_this_rate": bytes_pair * batches * B / dt / 1e9,
-            "pipeline": "pinned host uint8 images + host-sampled coordinates -> H2D on a copy stream (two buffer sets) -> extract_patches "
-                        "(normalise + gather) -> forward -> scores kept on the GPU -> validate.compute_correlations_cat_flat at the end",
+            "pipeline": "vtamiq_amd.pipeline.ImagePairPipeline: a host copy of the decoded uint8 images into pinned buffers + host-sampled coordinates "
+                        "-> H2D on a copy stream (two buffer sets) -> extract_patches (normalise + gather) -> forward -> scores kept on the GPU -> "
+                        "validate.compute_correlations_cat_flat at the end",
             "SROCC_of_the_synthetic_targets": corr["SROCC"]}
 
 

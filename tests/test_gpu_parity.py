@@ -749,3 +749,45 @@ def test_fused_layernorm_option_is_rejected_where_the_kernel_does_not_apply():
         sc = (torch.zeros(1, N, device=DEV),) * 2 if m.spec.use_scale_embedding else (None, None)
         with pytest.raises(RuntimeError, match="VTQ_OPT_FUSED_LAYERNORM"), torch.no_grad():
             m((p, p), (pos, pos), sc)
+
+
+@pytest.mark.parametrize("nscales", [1, 3])
+def test_image_pair_pipeline_matches_the_direct_path(nscales):
+    """vtamiq_amd.pipeline.ImagePairPipeline (pinned host buffers -> H2D on a copy stream -> on-device gather -> forward, two buffer
+    sets) over five batches -- the buffer sets wrap around twice -- against extract_patches + the model called directly on the same
+    images and samples: the same bits.  An out-of-range sample raises the loader's IndexError before anything is enqueued."""
+    from vtamiq_amd.patches import extract_patches
+    from vtamiq_amd.pipeline import ImagePairPipeline
+    kw = dict(vit_config=dict(variant="ViT-B16", num_keep_layers=2, num_scales=nscales if nscales > 1 else 0, pretrained=False))
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=MAIN)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(m.spec, 3).items()})
+    m = m.to(DEV).eval()
+    B, N, H, W = 3, 60, 96, 128
+    rs = np.random.RandomState(5)
+    pipe = ImagePairPipeline(m, B, (H, W), N, num_scales=nscales)
+    counts = synth.num_patches_per_scale(N, nscales) if nscales > 1 else np.array([N])
+    sid1 = np.concatenate([np.full(c, s) for s, c in enumerate(counts)]).astype(np.int32)
+    got, want = [], []
+    for it in range(5):
+        ref = rs.randint(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+        dist = rs.randint(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+        smp = np.zeros((B, N, 2), np.int32)
+        for s in range(nscales):
+            sel = sid1 == s
+            smp[:, sel, 0] = rs.randint(0, (H >> s) - 15, size=(B, int(sel.sum())))
+            smp[:, sel, 1] = rs.randint(0, (W >> s) - 15, size=(B, int(sel.sum())))
+        sid = np.broadcast_to(sid1, (B, N)).copy() if nscales > 1 else None
+        got.append(pipe.submit(ref, dist, smp, sid))
+        img = torch.from_numpy(np.concatenate([ref, dist])).to(DEV)
+        s2 = torch.from_numpy(np.concatenate([smp, smp])).to(DEV)
+        i2 = torch.from_numpy(np.concatenate([sid, sid])).to(DEV) if sid is not None else None
+        pa, po, sc = extract_patches(img, s2, i2, nscales)
+        with torch.no_grad():
+            want.append(m((pa[:B], pa[B:]), (po[:B], po[B:]), (sc[:B], sc[B:]) if sc is not None else (None, None))[0])
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    bad = smp.copy()
+    bad[0, 0, 0] = H                                        # one row past the image
+    with pytest.raises(IndexError):
+        pipe.submit(ref, dist, bad, sid)

@@ -24,7 +24,9 @@
 //     ln_row's, so the planes are bit-identical to layernorm_kernel's (tests/test_gpu_kernels.py compares them bitwise).
 //   * epilogue: eight passes of 16 rows through two fp32 LDS images (row pitch 3088 B: conflict-free ds_write_b128 from the accumulator
 //     registers -- AGPRs are read by the LDS instruction directly); a wave then owns 4 WHOLE rows of the pass: 3 float4 per lane, the
-//     residual row prefetched one pass ahead, two wave reductions, x stored as 1-KiB row segments and the planes as 512-B segments.
+//     residual row brought into LDS by LDS-DMA one pass ahead, two wave reductions, x stored as 1-KiB row segments, the planes as 512-B ones.
+//   * measured (profiles/r04_rowln_*.txt): bit-identical and NOT faster than the two launches it replaces -- out-proj ties,
+//     fc2 is 7 % slower -- so the engine uses it only under vtq_config.options & VTQ_OPT_FUSED_LAYERNORM.
 #include <mutex>
 
 #include "dev_common.h"
@@ -50,26 +52,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wave-uniform run-time count (the last 16 column-block steps of a tile, where fewer requests are behind the one waited for)
-__device__ __forceinline__ void wait_vm_rt(int n) {
-    switch (n) {
-#define VTQ_C(k) case k: wait_vm<k>(); break;
-        VTQ_C(0) VTQ_C(1) VTQ_C(2) VTQ_C(3) VTQ_C(4) VTQ_C(5) VTQ_C(6) VTQ_C(7) VTQ_C(8) VTQ_C(9) VTQ_C(10) VTQ_C(11) VTQ_C(12) VTQ_C(13) VTQ_C(14) VTQ_C(15)
-        VTQ_C(16) VTQ_C(17) VTQ_C(18) VTQ_C(19) VTQ_C(20) VTQ_C(21) VTQ_C(22) VTQ_C(23) VTQ_C(24) VTQ_C(25) VTQ_C(26) VTQ_C(27) VTQ_C(28) VTQ_C(29)
-#undef VTQ_C
-        default: wait_vm<30>(); break;
-    }
-}
-
-// The three MFMAs of one product term set on an accumulator block living in the AGPR half (AG) or the VGPR half of the register file:
-//     c += w_hi a_hi;  c += w_hi a_lo;  c += w_lo a_hi      (gemm_pp2_kernel's order)
-// as ONE asm statement with the accumulator constrained "+a" / "+v".  AGPR blocks: the 64 of them fill the 256 AGPRs exactly, the compiler
-// has nowhere to move them and nothing of its own reads them before the epilogue's padded hand-over.  VGPR blocks: the compiler DOES move
-// those between registers (v_mov_b64 at loop edges), and hipcc pads the MFMA -> VALU hazard only for an MFMA it knows -- first light of this
-// kernel had 2 048 wrong elements in column block 11, copies that read two of the four result registers too early.  The statement
-// therefore ends with the wait states a 4-pass MFMA needs before any reader or writer of its result (cdna_hip_programming.md 5.7 item 2),
-// and every statement opens with the two states between a VALU / v_accvgpr_write of an operand (the lazily placed bias initialisation of
-// the accumulators) and the MFMA reading it.  Both ride in the previous MFMA's 16 cycles.
 #ifndef VTQ_RL_PRE
 #define VTQ_RL_PRE "s_nop 1\n\t"       // measurement builds may empty these two (wrong results possible)
 #endif
