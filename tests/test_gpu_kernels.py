@@ -233,6 +233,41 @@ def _attention_case(lib, fmt, nseq, S, H, packed, spike_row=None):
 
 
 @pytest.mark.parametrize("fmt", ["fp16x3", "fp16", "bf16x3"])
+@pytest.mark.parametrize("nseq,S", [(24, 501), (5, 9), (6, 64), (4, 521), (3, 130)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_is_not_reached_by_nan_rows_of_the_next_sequence(fmt, nseq, S, variant):
+    """Sequences are packed back to back, so the masked keys of a sequence's last key tile are the first rows of the NEXT sequence.  Their
+    probabilities are 0, but 0 x NaN = NaN: the kernels zero the V rows of masked keys in the tile's LDS image.  With every row of sequence
+    k (and the slack rows behind the last sequence) set to NaN / inf, the outputs of all OTHER sequences are the same bits as without."""
+    lib = _lib.load()
+    H = 768
+    rows = nseq * S + 128
+    qkv = _randn(rows, 3 * H, seed=41, scale=1.5)
+    P = to_planes(qkv, fmt, "a")
+    npl = P.shape[0]
+    lib.vtq_debug_attention_variant(variant)
+    try:
+        clean = torch.zeros((npl, rows, H), dtype=elt_dtype(fmt), device=DEV)
+        _lib.check(lib.vtq_k_attention(P.data_ptr(), rows * 3 * H, clean.data_ptr(), rows * H, nseq, S, S, H, num_code(fmt), stream()))
+        k = nseq // 2
+        Pb = P.clone()
+        Pb[:, k * S:(k + 1) * S] = float("nan")
+        Pb[:, nseq * S:] = float("inf")                       # the rows behind the last sequence (its last tile reads them)
+        dirty = torch.zeros_like(clean)
+        _lib.check(lib.vtq_k_attention(Pb.data_ptr(), rows * 3 * H, dirty.data_ptr(), rows * H, nseq, S, S, H, num_code(fmt), stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.vtq_debug_attention_variant(-1)
+    for s_ in range(nseq):
+        a, b = clean[:, s_ * S:(s_ + 1) * S].view(torch.int16), dirty[:, s_ * S:(s_ + 1) * S].view(torch.int16)
+        if s_ == k:
+            assert bool(torch.isnan(dirty[:, s_ * S:(s_ + 1) * S].float()).all())
+        else:
+            assert torch.equal(a, b), s_
+            assert bool(torch.isfinite(dirty[:, s_ * S:(s_ + 1) * S].float()).all())
+
+
+@pytest.mark.parametrize("fmt", ["fp16x3", "fp16", "bf16x3"])
 @pytest.mark.parametrize("nseq,S,H", [(24, 501, 768), (6, 1025, 1024), (3, 257, 768), (2, 2501, 768), (7, 64, 768)])
 def test_attention_kernels_agree_bitwise(fmt, nseq, S, H):
     """The two kernels run the same arithmetic in the same order per query row: identical bits, also with the row maximum moving late and

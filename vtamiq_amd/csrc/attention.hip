@@ -186,8 +186,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 
     // two K/V buffers: tile t+1 is in flight while tile t is consumed, one barrier per tile
     const int nt = (S + KT - 1) / KT;          // the last tile may run into the next sequence's rows: keys >= S are masked
+    // The masked keys' probabilities are exactly 0, but their V rows belong to the NEXT sequence (sequences are packed back to back): a NaN /
+    // inf there would reach this sequence through 0 x NaN.  Every thread therefore zeroes, in the LDS image of the LAST key tile, the V pieces
+    // it staged itself whose row is a masked key -- after its DMA has landed (the vmcnt wait), before the barrier that publishes the tile.
+    // (K needs nothing: a NaN score of a masked key is replaced by -inf with a select.)
+    const int tail_valid = S - (nt - 1) * KT;   // real keys in the last tile (1 .. 64)
+    auto zero_masked_v = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+            const int row = (r * 256 + tid) >> 3;
+            if (row >= tail_valid) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(smem + buf * STAGE + (NPL + pl) * TB + r * 4096 + tid * 16)), "v"(z) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef VTQ_ATTN_NO_VMASK                          // measurement builds only: the cost of the masked-key V rows' zeroing (A/B)
+    if (nt == 1) zero_masked_v(0);
+#endif
     __syncthreads();
     int cur = 0;
 #ifdef VTQ_ATTN_DIAG
@@ -318,6 +340,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 
         VTQ_AT_SPAN(dg_pv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 has landed
+#ifndef VTQ_ATTN_NO_VMASK
+        if (t + 2 == nt) zero_masked_v(nxt);                // ... and it is the last one: its masked keys' V rows become zeros
+#endif
         __syncthreads();
         VTQ_AT_SPAN(dg_bar);
         cur = nxt;
@@ -778,8 +803,27 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     };
     auto ahead_of = [](int G, int end) constexpr { return sw_ahead<NSPLIT>(G, end); };
 
+    // Masked keys (see attention_kernel zero_masked_v): tile g of this workgroup's stream is the last tile of its block iff g % nt == nt - 1;
+    // every thread zeroes its own V piece of such a tile (row d_row of the tile, one 16-byte piece per plane, at byte tid * 16 of the slot's V
+    // planes) when that row is a masked key -- behind the wait that lands the piece, in front of the barrier that publishes the tile.
+    const int tail_valid = S - (nt - 1) * KT;
+    auto zero_masked_v = [&](int g) __attribute__((always_inline)) {
+        if (d_row >= tail_valid) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + (uint32_t)((g & 3) * STAGE + (NPL + pl) * TB + tid * 16)), "v"(z) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     // ---- pipeline prologue: S(0) = QK^T of tile 0 and its softmax, no overlap ---------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ib2 = 2 % nt;                                        // in-block index of tile tau + 2 (tau = 0 here), kept by increments
+#ifndef VTQ_ATTN_NO_VMASK
+    for (int g = 0; g < 3 && g < NT; ++g)
+        if (g % nt == nt - 1) zero_masked_v(g);             // tiles 0 .. 2 were staged above and have landed
+#endif
     pp_barrier();
     {
         uint32_t kaddr[4];
@@ -977,6 +1021,11 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         VTQ_AT_SPAN(dg_rest);
         if (sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everything older than tile tau + 3 has landed: tile tau + 2 (its V is read two iterations from now) gets its masked rows zeroed
+#ifndef VTQ_ATTN_NO_VMASK
+        if (tau + 2 < NT && ib2 == nt - 1) zero_masked_v(tau + 2);
+        ib2 = (ib2 + 1 == nt) ? 0 : ib2 + 1;                   // in-block index of tile tau + 3, for the next iteration
+#endif
         pin_q(qf);
         if constexpr (NSPLIT == 3) { if (q_loaded && !q_log2) prescale_q<T>(qf, sc); }
         pp_barrier();

@@ -351,6 +351,8 @@ class VTAMIQ(nn.Module):
                     self._auto_fallback = False
                     warnings.warn("[VTAMIQ] non-finite scores: the inputs or weights of this call hold inf / NaN (both the fp16x3 and "
                                   "the bf16x3 forward overflowed); the model stays in precision 'fp16x3'")
+                    launch(self._ensure_engine(device))     # the scores handed back are the parity mode's (the healthy pairs' bits included)
+                    flags2 = (flags2 & 1) | (self._read_flags() & 1)
                 else:
                     warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
                                   f"{AUTO_FIRST!r}: this model now runs {AUTO_FALLBACK!r} (fp32 operand range, the same 3-MFMA "
