@@ -508,8 +508,14 @@ __device__ __forceinline__ void split_p4(const float (&p)[4], uint32_t (&hw)[2],
 
 // LDS reads of fragment group G of a tile (QK^T groups 0..7: K hi [+ lo] by ds_read_b128; PV groups 8..15: V^T hi [+ lo] by two
 // ds_read_b64_tr_b16 each), and the reads still in flight when group G is consumed: those of the next VTQ_SW_DIST groups below `end`
+#ifndef VTQ_SW_HALFREADS
+#define VTQ_SW_HALFREADS 0            // measurement builds: every second fragment group is not read (its registers keep the previous group's): what
+#endif                                //   a kernel with HALF the K / V fragment reads per MFMA -- 64 query rows per wave -- could save at most (results wrong)
 template <int NSPLIT>
-constexpr int sw_reads(int G) { return G < 8 ? (NSPLIT == 1 ? 1 : 2) : (G < 16 ? (NSPLIT == 1 ? 2 : 4) : 0); }
+constexpr int sw_reads(int G) {
+    if (VTQ_SW_HALFREADS && (G & 1)) return 0;
+    return G < 8 ? (NSPLIT == 1 ? 1 : 2) : (G < 16 ? (NSPLIT == 1 ? 2 : 4) : 0);
+}
 template <int NSPLIT>
 constexpr int sw_ahead(int G, int end) {
     int n = 0;
@@ -798,6 +804,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
 
     auto issue_g = [&](auto Gc, const uint32_t (&kaddr)[4], const uint32_t (&vaddr)[2]) __attribute__((always_inline)) {   // group G of a tile
         constexpr int G = decltype(Gc)::value;
+        if constexpr (VTQ_SW_HALFREADS && (G & 1)) return;
         if constexpr (G < 8) issue_k(std::integral_constant<int, G>{}, kaddr);
         else if constexpr (G < 16) issue_v(std::integral_constant<int, G - 8>{}, vaddr);
     };
