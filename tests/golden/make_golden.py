@@ -364,6 +364,15 @@ def run_ladder_case(name, vtamiq_kwargs, images, N, wseed, iseed, stress_qk, chu
     print(f"{name}: {B} scores, rms {np.sqrt(np.mean(out['q64'] ** 2)):.4f}; reference fp32 vs its own fp64: max {d.max():.2e}, p95 {np.percentile(d, 95):.2e}")
 
 
+def run_fullsize():
+    """Scores only, at the sizes bench.py runs: BASELINE configs[1] (B = 32, N = 500, ViT-B/16 L = 12) and the reference-default topology row
+    (train_config.py:169-194: L = 6, 8 registers, LayerScale, r = 16; B = 16, N = 512), flat seeded weights, through the reference (round 4)."""
+    run_case("c2_b32_n500", dict(vit_config=dict(variant="ViT-B16")), B=32, N=500, wseed=51, iseed=61)
+    run_case("refdefault_b16_n512",
+             dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, path_drop_prob=0.1, num_scales=0),
+                  ca_reduction=16, rg_path_drop=0.1, predictor_dropout=0.1), B=16, N=512, wseed=52, iseed=62)
+
+
 def run_ladder():
     run_ladder_case("stress5_b64_n500", dict(vit_config=dict(variant="ViT-B16")), images=8, N=500, wseed=32, iseed=777, stress_qk=5.0)
 
@@ -390,6 +399,9 @@ def main():
         run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
         run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--fullsize":       # only the two full-size score goldens (added in round 4; ~3 min)
+        run_fullsize()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--ladder":         # only the 64-pair N = 500 trained-like case (added in round 4; ~10 min)
         run_ladder()
         return
@@ -415,6 +427,7 @@ def main():
              B=2, N=40, wseed=22, iseed=19)
     run_stress()
     run_ladder()
+    run_fullsize()
     run_ops()
     run_npz()
     run_plumbing()

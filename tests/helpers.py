@@ -32,6 +32,9 @@ def load_case(name):
     return g, kw, spec, sd, (patches, pos, scales)
 
 
+# the sizes bench.py runs, scored by the reference (scores only): BASELINE configs[1] and the reference-default topology row
+FULLSIZE_CASES = ["c2_b32_n500", "refdefault_b16_n512"]
+
 LADDER_CASES = ["stress5_b64_n500"]       # 64 pairs at the BASELINE patch count on trained-like weights: scores only (fp32 + float64)
 
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, LADDER_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
+from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
 import os
 
 # fp32 op-order differences between the restatement and the reference modules stay below this
@@ -20,6 +20,21 @@ def test_e2e_q(name):
     e = rel_err(q.numpy(), g["q"])
     assert e["max_rel_rms"] < ORACLE_RTOL, e
     assert e["max_abs"] < 1e-6, e
+
+
+@pytest.mark.parametrize("name", FULLSIZE_CASES)
+def test_e2e_q_at_the_bench_sizes(name):
+    """The reference's scores at the sizes bench.py runs (B = 32, N = 500, L = 12; reference-default topology B = 16, N = 512): a bounded
+    sample here (pairs are independent: the first 3), the GPU test scores the whole batch.  Bound: on the flat init the B = 32, L = 12
+    scores are small through cancellation (rms 7e-3) and BOTH fp32 evaluations sit 4e-5 of that rms from the float64 scores (reference
+    3.7e-5, oracle 4.6e-5, measured over 4 pairs), so fp32 against fp32 is gated at 1.5e-4 of the rms; the L = 6 case meets 2e-5."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    n = 3
+    p, ps, sc = split_inputs(patches[:n], pos[:n], scales[:n] if scales is not None else None)
+    q = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)[0].numpy()
+    e = rel_err(q, g["q"][:n])
+    tol = 1.5e-4 if name == "c2_b32_n500" else ORACLE_RTOL
+    assert e["max_abs"] < tol * float(np.sqrt(np.mean(g["q"] ** 2))) and e["max_abs"] < 1e-6, e
 
 
 @pytest.mark.parametrize("name", STRESS_CASES)
