@@ -1,5 +1,4 @@
 """Helpers for the -m gpu tests: call the C ABI with torch device tensors."""
-import ctypes as C
 
 import torch
 

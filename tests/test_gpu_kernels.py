@@ -1,5 +1,4 @@
 """Per-kernel parity on the GPU, through the C ABI, against fp64 torch references of the same op."""
-import math
 
 import pytest
 import torch

@@ -32,7 +32,6 @@ for _ in range(10): check_samples_host(hs, None, 384, 512)
 print(f"check_samples_host: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
 
 # ---- the loop by elimination ----------------------------------------------------------------------------------------
-import json
 from vtamiq_amd import VTAMIQ, synth
 B, N, H, W = 32, 500, 384, 512
 m = VTAMIQ(vit_config=dict(variant="ViT-B16", pretrained=False), precision="fp16x3")
