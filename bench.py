@@ -398,6 +398,9 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    # dmabuf IPC is the only form this pool's host driver supports (RCCL across processes fails with the legacy one); already exported
+    # on the boxes, kept here for a launcher that built its own environment
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
