@@ -373,6 +373,12 @@ def run_fullsize():
                   ca_reduction=16, rg_path_drop=0.1, predictor_dropout=0.1), B=16, N=512, wseed=52, iseed=62)
 
 
+def run_fullsize_c4():
+    """BASELINE configs[3] whole: ViT-L/16 (H = 1024, L = 24, 16 heads), B = 16 pairs, N = 1024 patches over 3 scales (738 / 220 / 66), through
+    the reference; scores only (round 4; ~10 min of CPU)."""
+    run_case("c4_vitl_b16_n1024", dict(vit_config=dict(variant="ViT-L16", num_scales=3)), B=16, N=1024, wseed=53, iseed=63)
+
+
 def run_ladder():
     run_ladder_case("stress5_b64_n500", dict(vit_config=dict(variant="ViT-B16")), images=8, N=500, wseed=32, iseed=777, stress_qk=5.0)
 
@@ -402,6 +408,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--fullsize":       # only the two full-size score goldens (added in round 4; ~3 min)
         run_fullsize()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--fullsize-c4":
+        run_fullsize_c4()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--ladder":         # only the 64-pair N = 500 trained-like case (added in round 4; ~10 min)
         run_ladder()
         return
@@ -428,6 +437,7 @@ def main():
     run_stress()
     run_ladder()
     run_fullsize()
+    run_fullsize_c4()
     run_ops()
     run_npz()
     run_plumbing()

@@ -33,7 +33,7 @@ def load_case(name):
 
 
 # the sizes bench.py runs, scored by the reference (scores only): BASELINE configs[1] and the reference-default topology row
-FULLSIZE_CASES = ["c2_b32_n500", "refdefault_b16_n512"]
+FULLSIZE_CASES = ["c2_b32_n500", "refdefault_b16_n512", "c4_vitl_b16_n1024"]     # the last: BASELINE configs[3] whole (ViT-L/16, 3 scales)
 
 LADDER_CASES = ["stress5_b64_n500"]       # 64 pairs at the BASELINE patch count on trained-like weights: scores only (fp32 + float64)
 

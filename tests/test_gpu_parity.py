@@ -60,8 +60,9 @@ def test_golden(name, precision):
 @pytest.mark.parametrize("name", FULLSIZE_CASES)
 def test_golden_at_the_bench_sizes(name, precision):
     """The whole batch at the sizes bench.py times -- BASELINE configs[1] (B = 32, N = 500, ViT-B/16 L = 12) and the reference-default
-    topology (L = 6, 8 registers, LayerScale, r = 16; B = 16, N = 512) -- against scores the REFERENCE produced for the same seeded
-    inputs (tests/golden/make_golden.py --fullsize).  The parity mode (and `auto`, which must resolve to it) meets the raw per-score gate
+    topology (L = 6, 8 registers, LayerScale, r = 16; B = 16, N = 512) -- and BASELINE configs[3] whole (ViT-L/16, L = 24, B = 16,
+    N = 1024 over 3 scales), against scores the REFERENCE produced for the same seeded inputs (tests/golden/make_golden.py
+    --fullsize / --fullsize-c4).  The parity mode (and `auto`, which must resolve to it) meets the raw per-score gate
     on both.  The throughput modes are gated on the error relative to the batch's rms: the flat-init L = 12 scores of 32 pairs are
     small through cancellation (rms 7e-3, individual scores down to 0.12 rms; both fp32 evaluations are themselves 4e-5 of the rms
     from float64, tests/test_oracle_golden.py), and a raw relative error on such a score measures the cancellation, not the mode."""

@@ -24,12 +24,13 @@ def test_e2e_q(name):
 
 @pytest.mark.parametrize("name", FULLSIZE_CASES)
 def test_e2e_q_at_the_bench_sizes(name):
-    """The reference's scores at the sizes bench.py runs (B = 32, N = 500, L = 12; reference-default topology B = 16, N = 512): a bounded
+    """The reference's scores at the sizes bench.py runs (B = 32, N = 500, L = 12; reference-default topology B = 16, N = 512) and at BASELINE
+    configs[3] (ViT-L/16, B = 16, N = 1024, 3 scales): a bounded
     sample here (pairs are independent: the first 3), the GPU test scores the whole batch.  Bound: on the flat init the B = 32, L = 12
     scores are small through cancellation (rms 7e-3) and BOTH fp32 evaluations sit 4e-5 of that rms from the float64 scores (reference
     3.7e-5, oracle 4.6e-5, measured over 4 pairs), so fp32 against fp32 is gated at 1.5e-4 of the rms; the L = 6 case meets 2e-5."""
     g, kw, spec, sd, (patches, pos, scales) = load_case(name)
-    n = 3
+    n = 1 if name.startswith("c4_") else 3          # one ViT-L pair at N = 1024 is 1.4 TFLOP of host work
     p, ps, sc = split_inputs(patches[:n], pos[:n], scales[:n] if scales is not None else None)
     q = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)[0].numpy()
     e = rel_err(q, g["q"][:n])
