@@ -16,6 +16,19 @@ def _randn(*s, seed=0, scale=1.0):
 
 
 FMTS = ["bf16", "bf16x3", "fp16", "fp16x2", "fp16x3"]
+# tile shapes of a GEMM launch (include/vtamiq_hip.h vtq_debug_gemm_variant): the library's rule, the persistent 256x256 kernel, and the
+# small tiles of csrc/gemm_st.hip
+TILE_RULE, TILE_256, TILE_ST = -1, 0, (1, 2, 3)
+
+
+@pytest.fixture(params=[TILE_RULE, TILE_256], ids=["tile_rule", "tile_256"])
+def tile(request):
+    """Run a GEMM test twice: with the shape the library's rule picks for it (small-tile kernels for these small M) and with the
+    persistent 256x256 kernel forced."""
+    lib = _lib.load()
+    _lib.check(lib.vtq_debug_gemm_variant(request.param))
+    yield request.param
+    _lib.check(lib.vtq_debug_gemm_variant(TILE_RULE))
 # error of a 16-bit OUTPUT relative to the tensor's max: one plane rounds to 8 / 11 bits, two planes carry 16 / 22
 OUT_TOL = {"bf16": 1e-2, "fp16": 2e-3, "bf16x3": 1e-4, "fp16x2": 2e-5, "fp16x3": 2e-5}
 
@@ -37,7 +50,7 @@ def test_split(fmt, role):
 
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 768), (512, 768, 768), (768, 2304, 768), (256, 768, 3072), (512, 1024, 1024), (2048, 1024, 256)])
-def test_gemm_bias(fmt, M, N, K):
+def test_gemm_bias(fmt, M, N, K, tile):
     lib = _lib.load()
     A, W, bias = _randn(M, K, seed=2), _randn(N, K, seed=3, scale=0.05), _randn(N, seed=4)
     Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
@@ -77,7 +90,7 @@ def test_gemm_many_tiles_per_workgroup(fmt):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
-def test_gemm_gelu(fmt):
+def test_gemm_gelu(fmt, tile):
     lib = _lib.load()
     M, N, K = 256, 3072, 768
     A, W, bias = _randn(M, K, seed=5), _randn(N, K, seed=6, scale=0.05), _randn(N, seed=7)
@@ -95,7 +108,7 @@ def test_gemm_gelu(fmt):
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("use_gamma", [False, True])
 @pytest.mark.parametrize("M", [512, 256 * 41])
-def test_gemm_residual(fmt, use_gamma, M):
+def test_gemm_residual(fmt, use_gamma, M, tile):
     lib = _lib.load()
     N, K = 768, 3072 if M == 512 else 768
     A, W, bias = _randn(M, K, seed=8), _randn(N, K, seed=9, scale=0.02), _randn(N, seed=10)
@@ -110,6 +123,48 @@ def test_gemm_residual(fmt, use_gamma, M):
     h = planes_value(Ap)[rows] @ planes_value(Wp).t() + bias.double()
     ref = x0[rows].double() + (gamma.double() * h if use_gamma else h)
     assert (x[rows].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (1024, 768, 3072), (1280, 2304, 768), (512, 1024, 256)])
+def test_gemm_tile_shapes_agree_bitwise(fmt, epi, M, N, K):
+    """The bitwise contract of csrc/gemm_st.hip: every tile shape gives every output element the MFMA sequence and the epilogue
+    arithmetic of the 256x256 kernel, so the outputs are IDENTICAL -- which is what lets vtq_k_gemm_tile_rule choose by (M, N) without
+    the scores depending on the batch size."""
+    lib = _lib.load()
+    A, W, bias, gamma = _randn(M, K, seed=41), _randn(N, K, seed=42, scale=0.05), _randn(N, seed=43), _randn(N, seed=44)
+    x0 = _randn(M, N, seed=45)
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    outs = {}
+    try:
+        for v in (TILE_256,) + TILE_ST:
+            _lib.check(lib.vtq_debug_gemm_variant(v))
+            out = torch.zeros((Ap.shape[0], M, N), dtype=elt_dtype(fmt), device=DEV)
+            x = x0.clone()
+            for _ in range(2 if epi != 2 else 1):          # a second launch over the same output: same bits again
+                _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), epi, bias.data_ptr(),
+                                          gamma.data_ptr() if epi == 2 else None, x.data_ptr() if epi == 2 else None,
+                                          out.data_ptr() if epi != 2 else None, M * N, N, stream()))
+            torch.cuda.synchronize()
+            outs[v] = x if epi == 2 else out
+    finally:
+        _lib.check(lib.vtq_debug_gemm_variant(TILE_RULE))
+    base = outs[TILE_256]
+    assert bool(torch.isfinite(base.float()).all()) and float(base.float().abs().max()) > 0
+    for v in TILE_ST:
+        assert torch.equal(outs[v].view(torch.int32 if epi == 2 else torch.int16), base.view(torch.int32 if epi == 2 else torch.int16)), (v, fmt, epi)
+
+
+def test_gemm_tile_rule():
+    """Host-only rule: small tiles only while the 256x256 form would leave most CUs idle; never for fp8 operands."""
+    lib = _lib.load()
+    rule = lambda M, N, K, fmt="fp16x3": lib.vtq_k_gemm_tile_rule(M, N, K, _lib.NUM[fmt])
+    assert rule(1024, 768, 3072) == 1 and rule(2048, 768, 768) == 2 and rule(4096, 768, 3072) == 3        # B = 1, 2, 4 pairs: out-proj / fc2
+    assert rule(1024, 2304, 768) == 3 and rule(1024, 3072, 768) == 3                                       # B = 1: QKV, fc1
+    assert rule(2048, 2304, 768) == 0 and rule(8192, 768, 768) == 0 and rule(32256, 768, 768) == 0         # 64 tiles of 256x256 and up
+    assert rule(1024, 768, 768, "fp8") == 0 and rule(1024, 768, 768, "bf16") == 1
+    assert lib.vtq_k_gemm_tile_rule(1024, 768, 768, 99) == -1
 
 
 @pytest.mark.parametrize("fmt", ["fp16x3", "bf16x3"])

@@ -650,6 +650,32 @@ def test_attention_kernels_agree_end_to_end(name, precision):
     assert gate(got[1], g["q"], TOL[precision]), rel_err(got[1], g["q"])
 
 
+@pytest.mark.parametrize("name,precision", [("c2shape_b4_n500", "fp16x3"), ("vitl_b2_n70", "fp16x3"), ("scales3_b2_n40", "bf16x3"),
+                                            ("adapters_b2_n40", "fp16x3"), ("refdefault_b2_n64", "fp16x2"), ("vitb8_b2_n90", "fp16"), ("c1_b2_n50", "bf16")])
+def test_gemm_tile_shapes_agree_end_to_end(name, precision):
+    """The library's rule gives small batches the small-tile GEMM kernels (csrc/gemm_st.hip) and chip-filling ones the persistent
+    256x256 kernel; forced to any one shape -- patch embedding, QKV, out-proj, fc1, fc2 and the adapter GEMMs alike -- a forward's scores
+    are the same bits (the bitwise contract that makes the choice a pure speed choice), and 8 repeated forwards per shape repeat."""
+    lib = _lib.load()
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    got = {}
+    for variant in (-1, 0, 1, 2, 3):
+        _lib.check(lib.vtq_debug_gemm_variant(variant))
+        try:
+            model = build(kw, sd, precision)
+            with torch.no_grad():
+                q = model(p, ps, sc)[0]
+                for _ in range(8):
+                    assert torch.equal(model(p, ps, sc)[0], q)
+            got[variant] = q.cpu().numpy()
+        finally:
+            _lib.check(lib.vtq_debug_gemm_variant(-1))
+    for variant, q in got.items():
+        assert np.array_equal(q, got[0]), variant
+    assert gate(got[-1], g["q"], TOL[precision]), rel_err(got[-1], g["q"])
+
+
 @pytest.mark.parametrize("precision", ["fp16x3", "fp16", "fp8"])
 def test_repeated_forwards_are_bitwise_identical(precision):
     """Race detector for the persistent GEMM (DMA ring chained across tile boundaries, counted vmcnt, raw barriers) and every other

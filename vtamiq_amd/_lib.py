@@ -57,6 +57,8 @@ SIGNATURES = {
     "vtq_debug_gemm_diag": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_attention_variant": (C.c_int, [C.c_int32]),
     "vtq_k_attention_rule": (C.c_int, [C.c_int32] * 5),
+    "vtq_debug_gemm_variant": (C.c_int, [C.c_int32]),
+    "vtq_k_gemm_tile_rule": (C.c_int, [C.c_int32] * 4),
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

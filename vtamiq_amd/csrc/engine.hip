@@ -848,6 +848,18 @@ int vtq_debug_attention_variant(int32_t v) {
     return 0;
 }
 
+int vtq_debug_gemm_variant(int32_t v) {
+    if (v < GEMM_TILE_AUTO || v > 31) return fail("vtq_debug_gemm_variant: %d", v);
+    gemm_set_variant(v);
+    return 0;
+}
+
+int vtq_k_gemm_tile_rule(int32_t M, int32_t N, int32_t K, int32_t num) {
+    const Num nm = num_from_code(num);
+    if (!num_valid(nm)) return -1;
+    return gemm_tile_rule(M, N, K, nm);
+}
+
 int vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus) {
     const Num nm = num_from_code(num);
     if (!num_valid(nm)) return -1;

@@ -1025,7 +1025,29 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
     return build_schedule(ntm, ntn, column_group(ntn, K, wpl));
 }
 
+namespace { int g_tile_variant = GEMM_TILE_AUTO; }
+void gemm_set_variant(int v) { g_tile_variant = v; }
+
+// Which tile shape serves an (M, N, K) launch (profiles/r05_gemm_tile_shapes.txt, fp16x3 on the encoder's four GEMMs at the row counts of
+// B = 1 .. 32 pairs).  The persistent 256x256 kernel wins from 64 of its tiles up (it is MFMA-bound per tile, the small tiles are bound by
+// a CU's L1 -> LDS fill rate: 4x the operand bytes per flop at 64x64); below that most CUs would idle, and one workgroup per small tile
+// is faster: 64x64 tiles while they fit one or two co-resident workgroups per CU, 128x128 beyond.  Pure speed choice (bitwise contract
+// of gemm_st.hip); fp8 operands have the 256x256 kernel only.
+int gemm_tile_rule(int M, int N, int K, Num num) {
+    if (num.f16 == 2 || M <= 0 || M % 256 || N <= 0 || N % 256 || K % 64) return GEMM_TILE_256;
+    const int t256 = (M / 256) * (N / 256);
+    if (t256 >= 64) return GEMM_TILE_256;
+    const int n64 = 16 * t256;
+    if (n64 <= kNumCus) return GEMM_ST_64;                 // one workgroup per CU, ring of 3
+    if (n64 <= 2 * kNumCus) return GEMM_ST_64X2;           // two co-resident workgroups per CU, ring of 2
+    return GEMM_ST_128;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) {
+    if (num_valid(num) && num.f16 != 2) {
+        const int v = g_tile_variant != GEMM_TILE_AUTO ? g_tile_variant : gemm_tile_rule(a.M, a.N, a.K, num);
+        if (v != GEMM_TILE_256) return launch_gemm_st(a, num, epilogue, v, s);
+    }
     const int bk2 = (num.f16 == 2) ? 256 : ((num.terms == 1) ? 128 : 64);     // two K tiles: the DMA ring's buffer parity is fixed across tiles
     if (a.M <= 0 || a.M % 256 || a.N % 256 || a.N > 4096 || a.K <= 0 || a.K % bk2 || a.lda % 16 || !num_valid(num)) return hipErrorInvalidValue;
     if (num.f16 == 2) {

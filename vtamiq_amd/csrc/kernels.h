@@ -58,7 +58,7 @@ struct PlaneOut { void* p; int64_t plane; int ld; int f16; int planes; const flo
 struct Fp8Obs { float* amax; int* err; };
 
 struct GemmArgs {
-    const void* A; int64_t a_plane; int lda;      // bf16 planes [M, lda]
+    const void* A; int64_t a_plane; int lda;      // 16-bit planes [M, lda]
     const void* W; int64_t w_plane;               // bf16 planes [N, K]
     int M, N, K;                                  // M % 256 == 0, N % 256 == 0, K % 128 == 0 (terms 1) | K % 64 == 0
     const float* bias;                            // [N]
@@ -87,6 +87,13 @@ __host__ __device__ constexpr int gemm_flags(const GemmArgs&) { return 0; }
 #endif
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
+// Tile shape of a GEMM launch.  launch_gemm picks one from (M, N, K, operand format) by gemm_tile_rule -- a pure speed choice: every
+// shape gives every output element the same MFMA sequence and epilogue arithmetic (gemm_st.hip "bitwise contract"), so results do not
+// depend on it.  GEMM_TILE_256: the persistent 256x256 / 128x256 kernel of gemm.hip; GEMM_ST_*: one workgroup per small tile (gemm_st.hip).
+enum { GEMM_TILE_AUTO = -1, GEMM_TILE_256 = 0, GEMM_ST_64 = 1, GEMM_ST_64X2 = 2, GEMM_ST_128 = 3 };
+hipError_t launch_gemm_st(const GemmArgs& a, Num num, int epilogue, int variant, hipStream_t s);
+int gemm_tile_rule(int M, int N, int K, Num num);     // host only: the shape launch_gemm would pick
+void gemm_set_variant(int v);                        // test / measurement hook: GEMM_TILE_AUTO (default) or a forced shape
 // Whole-row residual GEMM with LayerNorm in its epilogue (gemm_rowln.hip): x[M, 768] += gamma * (A W^T + bias), then (ln_w != NULL)
 // out planes = LayerNorm(x; ln_w, ln_b).  N = 768, 3-term operand formats, M % 128 == 0, K % 32 == 0.
 struct RowLnArgs {
