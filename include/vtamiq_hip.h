@@ -160,9 +160,10 @@ int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t
  * the partner wave's MFMAs costs).  Returns 1 in a diagnostic build. */
 int  vtq_debug_gemm_diag(void* buf, int32_t shadow);
 /* Which of the two fused-attention kernels vtq_k_attention and the engine launch (process-wide; tests and measurement):
- * 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel, -1 = the library's rule (the pipelined kernel for the 3-term
- * formats when its 256-row blocks fill the chip).  Both compute the same arithmetic
- * in the same order per query row: outputs are bit-identical. */
+ * 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel, 2 = split (the pipelined kernel on the full 256-row query blocks, the
+ * 4-wave kernel on the few rows behind them: S = 521, the reference-default topology), -1 = the library's rule (the pipelined kernel for
+ * the 3-term formats when its 256-row blocks fill the chip; split when S is at most 64 rows past a multiple of 256).  Every form
+ * computes the same arithmetic in the same order per query row: outputs are bit-identical. */
 int  vtq_debug_attention_variant(int32_t variant);
 /* Which tile shape vtq_k_gemm and the engine's GEMM launches use (process-wide; tests and measurement): -1 = the library's rule
  * (vtq_k_gemm_tile_rule), 0 = the persistent 256x256 kernel, 1 = 64x64 tiles, 2 = 128x128 tiles (one workgroup per tile,
@@ -171,7 +172,7 @@ int  vtq_debug_gemm_variant(int32_t variant);
 /* Host-only: the tile shape the library's rule gives an (M, N, K) launch in operand format num (VTQ_NUM_*); -1 = bad format code. */
 int  vtq_k_gemm_tile_rule(int32_t M, int32_t N, int32_t K, int32_t num);
 /* Host-only: which kernel the library's rule gives nseq sequences of pitch S_pad, hidden size H, operand format num (VTQ_NUM_*) on a
- * device with `cus` compute units: 1 = pipelined, 0 = 4-wave, -1 = bad format code. */
+ * device with `cus` compute units: 2 = split, 1 = pipelined, 0 = 4-wave, -1 = bad format code. */
 int  vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */

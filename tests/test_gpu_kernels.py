@@ -254,9 +254,11 @@ def _attention_ref(qkv, nseq, S, S_pad, H):
 @pytest.mark.parametrize("nseq,S,H", [(4, 501, 768), (3, 51, 768), (2, 1025, 1024), (2, 64, 768), (2, 509, 768), (5, 521, 768), (3, 9, 768),
                                       (2, 96, 768)])
 @pytest.mark.parametrize("packed", [True, False])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention(fmt, nseq, S, H, packed, variant):
-    """variant 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel (forced; the library's own rule picks per shape)."""
+    """variant 0 = the 4-wave kernel, 1 = the 8-wave software-pipelined kernel, 2 = split: the pipelined kernel on the full 256-row query
+    blocks and the 4-wave kernel on the rows behind them (forced; sequences shorter than 256 or a multiple of it run form 1; the
+    library's own rule picks per shape)."""
     lib = _lib.load()
     lib.vtq_debug_attention_variant(variant)
     try:
@@ -288,7 +290,7 @@ def _attention_case(lib, fmt, nseq, S, H, packed, spike_row=None):
 
 @pytest.mark.parametrize("fmt", ["fp16x3", "fp16", "bf16x3"])
 @pytest.mark.parametrize("nseq,S", [(24, 501), (5, 9), (6, 64), (4, 521), (3, 130)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_is_not_reached_by_nan_rows_of_the_next_sequence(fmt, nseq, S, variant):
     """Sequences are packed back to back, so the masked keys of a sequence's last key tile are the first rows of the NEXT sequence.  Their
     probabilities are 0, but 0 x NaN = NaN: the kernels zero the V rows of masked keys in the tile's LDS image.  With every row of sequence
@@ -322,25 +324,27 @@ def test_attention_is_not_reached_by_nan_rows_of_the_next_sequence(fmt, nseq, S,
 
 
 @pytest.mark.parametrize("fmt", ["fp16x3", "fp16", "bf16x3"])
-@pytest.mark.parametrize("nseq,S,H", [(24, 501, 768), (6, 1025, 1024), (3, 257, 768), (2, 2501, 768), (7, 64, 768)])
+@pytest.mark.parametrize("nseq,S,H", [(24, 501, 768), (6, 1025, 1024), (3, 257, 768), (2, 2501, 768), (7, 64, 768), (32, 521, 768), (5, 575, 768)])
 def test_attention_kernels_agree_bitwise(fmt, nseq, S, H):
-    """The two kernels run the same arithmetic in the same order per query row: identical bits, also with the row maximum moving late and
-    sitting in either half-wave (keys whose score lands in lanes 32..63 exposed a dropped v_permlane32_swap in round 3), on ragged last
-    blocks (257, 1025: one valid row in the last 256-row block) and across the block seams of a persistent workgroup (24 x 12 x 2 blocks)."""
+    """The two kernels -- and the split form that gives the rows behind the last full 256-row block to the 4-wave kernel (521: the
+    reference-default topology) -- run the same arithmetic in the same order per query row: identical bits, also with the row maximum
+    moving late and sitting in either half-wave (keys whose score lands in lanes 32..63 exposed a dropped v_permlane32_swap in round 3),
+    on ragged last blocks (257, 1025: one valid row in the last 256-row block) and across the block seams of a persistent workgroup."""
     lib = _lib.load()
-    outs = []
     for spike in (S - 3, S - 7 if S > 7 else 0):
-        for variant in (0, 1):
+        outs = []
+        for variant in (0, 1, 2):
             lib.vtq_debug_attention_variant(variant)
             try:
                 outs.append(_attention_case(lib, fmt, nseq, S, H, True, spike_row=spike).view(torch.int16).clone())
             finally:
                 lib.vtq_debug_attention_variant(-1)
-        assert torch.equal(outs[-2][:, : nseq * S], outs[-1][:, : nseq * S])
+        assert torch.equal(outs[0][:, : nseq * S], outs[1][:, : nseq * S])
+        assert torch.equal(outs[0][:, : nseq * S], outs[2][:, : nseq * S])
 
 
 @pytest.mark.parametrize("fmt", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_huge_logits(fmt, variant):
     """Scores of 1e12 .. 1e13 (Q, K of a 1e7-gain LayerNorm: the fp32 reference's softmax is finite there, train.py:602-607).  The
     exponent must subtract the row maximum exactly: exp2(s c - m c) as one FMA subtracts the ROUNDED product m c and returned inf
@@ -366,7 +370,7 @@ def test_attention_huge_logits(fmt, variant):
 
 
 @pytest.mark.parametrize("fmt", ["fp16", "bf16"])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_rows_do_not_depend_on_the_next_sequence(fmt, variant):
     """Packed sequences (pitch = S): the lanes of a ragged last query group hold the NEXT sequence's rows.  The single-plane formats'
     magnitude guard (|m c| > 64: subtract the maximum first) is a per-row decision -- a wave-wide one let a huge neighbour switch the

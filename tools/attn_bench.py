@@ -11,8 +11,10 @@ ap.add_argument("--nseq", type=int, default=64)
 ap.add_argument("--S", type=int, default=501)
 ap.add_argument("--H", type=int, default=768)
 ap.add_argument("--fmt", nargs="+", default=["bf16", "bf16x3", "fp16", "fp16x3"])
+ap.add_argument("--variant", type=int, default=-1, help="-1 the library's rule, 0 4-wave kernel, 1 pipelined kernel, 2 split")
 a = ap.parse_args()
 lib = _lib.load()
+lib.vtq_debug_attention_variant(a.variant)
 S_pad = a.S          # the engine packs sequences back to back
 rows = a.nseq * S_pad + 128
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -38,4 +40,4 @@ for fmt in a.fmt:
         ts.append(e0.elapsed_time(e1) / 5)
     ts.sort()
     fl = 4.0 * a.nseq * nh * a.S * a.S * 64
-    print(f"attention {fmt} nseq={a.nseq} S={a.S} H={a.H}: {ts[3]*1e3:.1f} us  {fl/ts[3]/1e9:.1f} TF algorithmic  err {err:.1e}")
+    print(f"attention {fmt} variant={a.variant} nseq={a.nseq} S={a.S} H={a.H}: {ts[3]*1e3:.1f} us  {fl/ts[3]/1e9:.1f} TF algorithmic  err {err:.1e}")

@@ -106,7 +106,9 @@ __device__ __forceinline__ void prescale_q(typename Vec<T>::x8 (&qf)[2][4], floa
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out,
                                                         int64_t o_plane, int S, int S_pad, int H, float out8_scale, Fp8Obs obs,
-                                                        unsigned long long* diag, int q_log2) {
+                                                        unsigned long long* diag, int q_log2, int q0, int Sq) {
+    // q0, Sq: this launch covers the query rows [q0, Sq) of every sequence (0, S_pad: all of them; launch_attention's split form gives
+    // the rows behind the last full 256-row block to this kernel)
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #endif
     // 1-D grid, XCD-aware: the q-blocks of one (sequence, head) re-read the same K/V, so they must share an L2.
     // Blocks are dealt round-robin over the 8 XCDs; remap so each XCD owns a contiguous range of work ids (bijective).
-    const int nqb = (S_pad + 127) / 128, nh = H / 64;
+    const int nqb = (Sq - q0 + 127) / 128, nh = H / 64;
     int wid = blockIdx.x;
     {
         const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7, idx = wid >> 3;
@@ -136,7 +138,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const int seq = wid / (nqb * nh);
     const int ld = 3 * H;
     const int64_t row0 = (int64_t)seq * S_pad;
-    const int q_row = qb * 128 + wave * 32 + c;
+    const int q_row = q0 + qb * 128 + wave * 32 + c;
+    // a wave whose 32 query rows all lie behind the sequence (ragged last block) stages and synchronises, nothing else
+    const bool wave_active = (q0 + qb * 128 + wave * 32) < S_pad;
 
     // ---- Q fragments: B operand of S^T = K Q^T, element j <-> d = 16t + 8hh + j ------------------------------
     tx8 qf[2][4];
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         const char* sk = smem + cur * STAGE;
         const char* sv = sk + NPL * TB;
 
+        if (wave_active) {
         // ---- S^T[key][q] for the 64 keys of this tile ---------------------------------------------------------
         f32x16 sacc[KB];
 #pragma unroll
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             }
 
         VTQ_AT_SPAN(dg_pv);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t+1 has landed
 #ifndef VTQ_ATTN_NO_VMASK
         if (t + 2 == nt) zero_masked_v(nxt);                // ... and it is the last one: its masked keys' V rows become zeros
@@ -527,7 +533,9 @@ constexpr int sw_ahead(int G, int end) {
 template <typename T, int NSPLIT>
 __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__ qkv, int64_t plane, T* __restrict__ out, int64_t o_plane,
                                                            int S, int S_pad, int H, int nblk, int per, float out8_scale, Fp8Obs obs,
-                                                           unsigned long long* diag, int q_log2) {
+                                                           unsigned long long* diag, int q_log2, int Sq) {
+    // Sq: this launch covers the query rows [0, Sq) of every sequence -- S_pad (all of them), or the full 256-row blocks only when
+    // launch_attention hands the short rest to the 4-wave kernel; S_pad stays the pitch of a sequence
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
     constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const int nqb = (S_pad + 255) / 256, nh = H / 64;
+    const int nqb = (Sq + 255) / 256, nh = H / 64;
     const int nt = (S + KT - 1) / KT;
     const int ld = 3 * H;
     // Blocks of this workgroup: b0, b0 + bstep, ... < b1.  With two query blocks per (sequence, head) and a grid that divides evenly,
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         int qb;
         const int64_t base = block_base(b, qb);
         int qr = qb * 256 + wave * 32 + c;
-        qr = qr < S_pad ? qr : S_pad - 1;
+        qr = qr < Sq ? qr : Sq - 1;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         int qb;
         const int64_t base = block_base(b, qb);
         int qr = qb * 256 + wave * 32 + c;
-        qr = qr < S_pad ? qr : S_pad - 1;
+        qr = qr < Sq ? qr : Sq - 1;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         const int q_row = qb * 256 + wave * 32 + c;
         const int64_t obase = block_out(b);
         if (out8_scale > 0.f) {                                    // fp8 mode: bytes, direct stores (one 64-byte piece per row)
-            if (q_row < S_pad && !VTQ_SW_NOSTORE) {
+            if (q_row < Sq && !VTQ_SW_NOSTORE) {
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
                     const int row = r_row + 8 * k;
                     const uint4 w = *(const uint4*)(o_stage + row * 128 + ((r_chunk ^ (row & 7)) << 4));
                     const int qr = qb * 256 + wave * 32 + row;
-                    if (qr < S_pad && !VTQ_SW_NOSTORE) *(uint4*)(out + pl * o_plane + obase + (int64_t)qr * H + 8 * r_chunk) = w;
+                    if (qr < Sq && !VTQ_SW_NOSTORE) *(uint4*)(out + pl * o_plane + obase + (int64_t)qr * H + 8 * r_chunk) = w;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are done before the next plane overwrites the image
             }
@@ -921,8 +929,8 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         }
         // waves whose 32 rows lie behind the sequence in the last query block of a (sequence, head) only load and synchronise
         const int qb_next = tb_next == 0 ? ((cqb + 1 == nqb) ? 0 : cqb + 1) : cqb;                  // query block of tile tau + 1
-        const bool active1 = (qb_next * 256 + wave * 32 < S_pad);
-        const bool active2 = (cqb * 256 + wave * 32 < S_pad);
+        const bool active1 = (qb_next * 256 + wave * 32 < Sq);
+        const bool active2 = (cqb * 256 + wave * 32 < Sq);
         // Q of the block after the one tile tau + 1 belongs to, when tile tau + 1 is that block's last: loaded into spare registers at
         // the top of the iteration whose phase 1 still needs the current Q, installed behind the end-of-iteration wait.
         // ---------------- phase 1: QK^T(tau + 1) -> sB  ||  split of P(tau) = sA, rescale of O ------------------------------
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
 
 template <typename T, int NSPLIT>
 hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
-                              float out8_scale, Fp8Obs obs, bool q_log2) {
+                              float out8_scale, Fp8Obs obs, bool q_log2, int q0 = 0) {
 #ifdef VTQ_ATTN_DIAG
     static const int lds_pad = VTQ_MEASURE_ENV("VTQ_ATTN_LDS_PAD") ? atoi(VTQ_MEASURE_ENV("VTQ_ATTN_LDS_PAD")) : 0;   // occupancy experiments
     const int LDS = 2 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2) + lds_pad;
@@ -1080,16 +1088,17 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
             configured[dev] = true;
         }
     }
-    const dim3 grid(((S_pad + 127) / 128) * (H / 64) * nseq), blk(256);
+    const dim3 grid(((S_pad - q0 + 127) / 128) * (H / 64) * nseq), blk(256);
     hipLaunchKernelGGL((attention_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, out8_scale, obs,
-                       gemm_diag_buffer(), q_log2 ? 1 : 0);
+                       gemm_diag_buffer(), q_log2 ? 1 : 0, q0, S_pad);
     return hipGetLastError();
 }
 
 // Pipelined kernel: persistent grid of at most one workgroup per CU (160 KB of LDS in the 3-term formats), `per` consecutive blocks each.
 template <typename T, int NSPLIT>
 hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
-                                 float out8_scale, Fp8Obs obs, int cus, bool q_log2) {
+                                 float out8_scale, Fp8Obs obs, int cus, bool q_log2, int Sq = 0) {
+    if (Sq <= 0) Sq = S_pad;
     constexpr int LDS = 4 * 2 * 64 * 128 * (NSPLIT == 1 ? 1 : 2) + 8 * 4096;     // K/V ring + output staging
     static std::mutex mu;
     static bool configured[64] = {false};
@@ -1105,11 +1114,11 @@ hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int6
             configured[dev] = true;
         }
     }
-    const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
+    const int nblk = ((Sq + 255) / 256) * (H / 64) * nseq;
     const int per = (nblk + cus - 1) / cus;
     const dim3 grid((nblk + per - 1) / per), blk(512);
     hipLaunchKernelGGL((attention_sw_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, nblk, per, out8_scale, obs,
-                       gemm_diag_buffer(), q_log2 ? 1 : 0);
+                       gemm_diag_buffer(), q_log2 ? 1 : 0, Sq);
     return hipGetLastError();
 }
 
@@ -1132,20 +1141,40 @@ static int device_cus(int* cus) {
 // persistent grid filled, and no more than 15 % more padded query rows than the 128-row blocks of the 4-wave kernel (waves without rows
 // skip their arithmetic, so padding costs the skeleton only: S = 1025 pads 11 % more rows and is 6 % faster; S = 257 pads 33 % more
 // and is 34 % slower).
-bool attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
-    if (terms != 3 || cus < 1 || nseq < 1 || S_pad < 1 || H % 64) return false;
-    const int nblk = ((S_pad + 255) / 256) * (H / 64) * nseq;
-    const int per = (nblk + cus - 1) / cus;
-    const bool fills = (double)nblk >= 0.85 * (double)per * cus;
+// SPLIT (2): a sequence a few rows longer than a multiple of 256 -- the reference's default topology is 512 patches + CLS + 8 register
+// tokens = 521 -- would pay a whole 256-row (or 128-row) block for those few rows; instead the pipelined kernel takes the full 256-row
+// blocks and ONE launch of the 4-wave kernel the rest (query rows [256 k, S); its waves without rows only stage).  Same arithmetic per
+// query row in every form: outputs are bit-identical (tests/test_gpu_kernels.py).
+int attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
+    if (terms != 3 || cus < 1 || nseq < 1 || S_pad < 1 || H % 64) return 0;
+    auto fills = [&](int rows) {
+        const int nblk = ((rows + 255) / 256) * (H / 64) * nseq;
+        const int per = (nblk + cus - 1) / cus;
+        return (double)nblk >= 0.85 * (double)per * cus;
+    };
+    const int full = (S_pad / 256) * 256, rest = S_pad - full;
+    if (full > 0 && rest > 0 && rest <= 64 && fills(full)) return 2;
     const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 115;
-    return fills && rows_ok;
+    return (fills(S_pad) && rows_ok) ? 1 : 0;
 }
 
-static bool use_pipelined(int nseq, int S_pad, int H, int terms, int cus) {
+static int pick_variant(int nseq, int S_pad, int H, int terms, int cus) {
     static const int env = VTQ_MEASURE_ENV("VTQ_ATTN_VARIANT") ? atoi(VTQ_MEASURE_ENV("VTQ_ATTN_VARIANT")) : -1;   // -DVTQ_MEASURE builds only
     const int forced = g_attn_variant >= 0 ? g_attn_variant : env;
-    if (forced >= 0) return forced == 1;
+    if (forced == 2) return (S_pad >= 256 && S_pad % 256) ? 2 : 1;      // forced split needs a full block and a rest
+    if (forced >= 0) return forced == 1 ? 1 : 0;
     return attention_rule(nseq, S_pad, H, terms, cus);
+}
+
+template <typename T, int NSPLIT>
+static hipError_t launch_attention_v(int variant, const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
+                                     hipStream_t s, float out8_scale, Fp8Obs obs, int cus, bool q_log2) {
+    if (variant == 0) return launch_attention_t<T, NSPLIT>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+    if (variant == 1) return launch_attention_sw_t<T, NSPLIT>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+    const int full = (S_pad / 256) * 256;
+    const hipError_t e = launch_attention_sw_t<T, NSPLIT>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2, full);
+    if (e != hipSuccess) return e;
+    return launch_attention_t<T, NSPLIT>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2, full);
 }
 
 hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H,
@@ -1154,20 +1183,13 @@ hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o
     if (q_log2 && num.terms != 3) return hipErrorInvalidValue;
     int cus = 0;
     if (device_cus(&cus) || cus < 1) return hipErrorInvalidDevice;
-    if (use_pipelined(nseq, S_pad, H, num.terms, cus)) {
-        if (!num.f16) {
-            if (num.terms == 1) return launch_attention_sw_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
-            return launch_attention_sw_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
-        }
-        if (num.terms == 1) return launch_attention_sw_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
-        return launch_attention_sw_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
-    }
+    const int v = pick_variant(nseq, S_pad, H, num.terms, cus);
     if (!num.f16) {
-        if (num.terms == 1) return launch_attention_t<bf16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
-        return launch_attention_t<bf16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+        if (num.terms == 1) return launch_attention_v<bf16, 1>(v, qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+        return launch_attention_v<bf16, 3>(v, qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
     }
-    if (num.terms == 1) return launch_attention_t<f16, 1>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
-    return launch_attention_t<f16, 3>(qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, q_log2);
+    if (num.terms == 1) return launch_attention_v<f16, 1>(v, qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
+    return launch_attention_v<f16, 3>(v, qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);
 }
 
 }  // namespace vtq

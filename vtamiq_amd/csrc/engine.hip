@@ -863,7 +863,7 @@ int vtq_k_gemm_tile_rule(int32_t M, int32_t N, int32_t K, int32_t num) {
 int vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus) {
     const Num nm = num_from_code(num);
     if (!num_valid(nm)) return -1;
-    return attention_rule(nseq, S_pad, H, nm.terms, cus) ? 1 : 0;
+    return attention_rule(nseq, S_pad, H, nm.terms, cus);
 }
 
 int vtq_debug_gemm_diag(void* buf, int32_t shadow) {

@@ -107,8 +107,8 @@ struct RowLnArgs {
 };
 hipError_t launch_gemm_rowln(const RowLnArgs& a, Num num, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
-bool attention_rule(int nseq, int S_pad, int H, int terms, int cus);   // host-only: would launch_attention pick the pipelined kernel?
-void attention_set_variant(int v);               // test / measurement hook: -1 default, 0 four-wave kernel, 1 ping-pong kernel
+int attention_rule(int nseq, int S_pad, int H, int terms, int cus);    // host-only: the form launch_attention picks: 0 four-wave kernel, 1 pipelined kernel, 2 split
+void attention_set_variant(int v);               // test / measurement hook: -1 the rule, 0 / 1 / 2 as above
 unsigned long long* gemm_diag_buffer();         // the buffer of gemm_set_diag (attention's diagnostic build shares it)
 void gemm_set_diag(unsigned long long* buf, int shadow);
 bool gemm_is_diag_build();
