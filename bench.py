@@ -221,10 +221,11 @@ def fc1_traffic(precision, B):
     """HBM bytes of ONE full-batch fc1 GEMM from the committed PMC passes (profiles/*_gemm_fc1_traffic.json: FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs at B=32), scaled linearly with the batch.  A committed
     measurement of the same kernel, not a counter read during this run (rocprofv3 is not on bench.py's path)."""
-    for name in ("r03_gemm_fc1_traffic.json", "r02_gemm_fc1_traffic.json", "r01_gemm_fc1_traffic.json"):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_fc1_traffic.json")), reverse=True):      # newest round first
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return d[precision]["bytes_per_launch"] * (B / 32.0), "profiles/" + name
+            d = json.load(open(path))
+            return d[precision]["bytes_per_launch"] * (B / 32.0), "profiles/" + os.path.basename(path)
         except Exception:
             continue
     return None, None
@@ -361,6 +362,63 @@ def cpu_baseline(torch, spec, sd_np, seconds_budget=40.0):
             "ms_per_forward": head["ms_per_forward"], "cases": cases}
 
 
+def practical_peak(precision, warm_s=1.0, timed_s=1.0):
+    """What the matrix pipe sustains on THIS device with the operand bits of this mode (vtq_debug_mfma_stream, csrc/mfma_stream.hip): a bare
+    stream of back-to-back 16x16x32 MFMAs on register operands on every CU, >= timed_s after >= warm_s of the same load.  3-term modes
+    stream the hi x hi / hi x lo / lo x hi mix of gaussian planes, single-plane modes uniform random data; zeros give the issue limit."""
+    import ctypes as C
+    import torch
+    from vtamiq_amd import _lib
+    if precision == "fp8":
+        return None
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    f16 = 1 if precision.startswith("fp16") else 0
+    data = 0 if precision.endswith(("x3", "x2")) else 2
+    out = {}
+    for key, d, w, t in (("operands_of_this_mode", data, warm_s, timed_s), ("zeros_issue_limit", 1, 0.3, 0.5)):
+        tf, ghz = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(lib.vtq_debug_mfma_stream(f16, d, w, t, C.byref(tf), C.byref(ghz), stream))
+        out[key] = {"tflops": tf.value, "implied_clock_ghz": ghz.value, "warm_s": w, "timed_s": t}
+    out["operands"] = ("3-term mix of gaussian hi / lo planes (hi x hi, hi x lo, lo x hi)" if data == 0 else "uniform random single planes") + \
+                      (", fp16" if f16 else ", bf16")
+    return out
+
+
+def latency_block(torch, make_model, precision, device, N, batches=(1, 2, 4, 8, 16), steps=20):
+    """The small-batch / single-query regime (the reference's own FLOP probe is batch 1 x 500 patches, modules/utils.py:68-78): ms per
+    forward with the forwards queued back to back (HIP events) and one at a time (the host waits for every score), and the forward's
+    fraction of the MFMA roofline, at B pairs x N patches on the bench model; GEMM launches with fewer than 64 tiles of 256x256 run the
+    small-tile kernels (csrc/gemm_st.hip), bit-identical scores (profiles/r05_small_batch.txt: B = 1 2.98 -> 1.60 ms)."""
+    m = make_model(precision)
+    spec = m.spec
+    rows = []
+    with torch.no_grad():
+        for Bc in batches:
+            inp = synth_inputs_on_device(torch, Bc, N, device, 9000 + Bc)
+            for _ in range(4):
+                m(*inp)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                m(*inp)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m(*inp)
+                torch.cuda.synchronize()
+            ms_sync = (time.perf_counter() - t0) / steps * 1e3
+            f = spec.flops_per_pair_executed(N, cls_prune=precision != "fp8")
+            rows.append({"batch": Bc, "token_rows": 2 * Bc * spec.seq_len(N), "ms_per_forward": ms, "ms_per_forward_synchronous": ms_sync,
+                         "pairs_per_s": Bc / ms * 1e3, "forward_mfma_frac": Bc / ms * 1e3 * f / (PEAK_BF16_TFLOPS * 1e12)})
+    del m
+    torch.cuda.empty_cache()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,6 +441,11 @@ def main():
     ap.add_argument("--no-collective-check", action="store_true", help="--gpus 1: skip the world-size-1 RCCL block")
     ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e` block (validation loop from host uint8 images)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reference-default-topology row (`secondary`)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the `latency` block (B = 1 .. 16 pairs per forward)")
+    ap.add_argument("--no-practical-peak", action="store_true", help="skip the in-run measurement of the matrix pipe's sustained rate")
+    ap.add_argument("--no-auto-overhead", action="store_true", help="skip timing the default-constructed model (precision='auto')")
+    ap.add_argument("--other-modes-multi-gpu", action="store_true",
+                    help="--gpus N > 1: also time the other numerics modes on every rank (triples the run; off by default there)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are stopped")
     # launcher self-test on CPU (tests/test_bench_launcher.py): gloo ranks + a stub model, no HIP anywhere
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
@@ -431,6 +494,23 @@ def main():
             collective = {"backend": "nccl (RCCL)", "world_size": 1}
         except Exception as e:                       # pragma: no cover
             collective = {"collective_executed": False, "error": f"init_process_group: {e!r}"[:300]}
+    # Multi-GPU first-try checklist: every rank reports the device it runs on; N distinct devices or no timing.
+    rank_devices = None
+    if on_gpu:
+        pr = torch.cuda.get_device_properties(device)
+        ident = {"rank": rank, "local_rank": local_rank, "device_index": device.index, "name": torch.cuda.get_device_name(device),
+                 "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0)),
+                 "uuid": str(getattr(pr, "uuid", "")), "cus": pr.multi_processor_count, "hbm_gib": round(pr.total_memory / 2 ** 30, 1)}
+    else:
+        ident = {"rank": rank, "local_rank": local_rank, "device_index": None, "name": "cpu (launcher self-test)", "pci_bus_id": f"cpu:{rank}", "uuid": f"cpu:{rank}"}
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, ident)
+        keys = {(d["pci_bus_id"], d["uuid"], d["device_index"]) for d in rank_devices}
+        assert len(keys) == world, f"{world} ranks on {len(keys)} distinct devices: {rank_devices}"
+        print(f"[bench] rank {rank}: device {ident['device_index']} {ident['name']} pci {ident['pci_bus_id']}", file=sys.stderr, flush=True)
+    else:
+        rank_devices = [ident]
     force_coll = bool(a.force_collective and collective is not None and "error" not in collective)
     if os.environ.get("VTQ_BENCH_FAIL_RANK") == str(rank):          # launcher test hook: this rank dies before the first collective
         sys.exit(3)
@@ -522,6 +602,8 @@ def main():
                               "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f32", "data": "stub", "rccl_ranks": rccl_ranks, "backend": a.backend,
+                              "rank_step_ms": {"min": min(rank_times) / a.steps * 1e3, "max": max(rank_times) / a.steps * 1e3},
+                              "rank_devices": rank_devices,
                               "config": {"workload": "stub", "global_batch": global_batch, "parallelism": f"dp{world}"},
                               "q_checksum": float(q.double().sum())})])
         if world > 1:
@@ -580,6 +662,16 @@ def main():
                                "allgather_us": allgather_us, "in_timed_step": force_coll})
         except Exception as e:                       # pragma: no cover
             collective = {"collective_executed": False, "error": f"{e!r}"[:300]}
+    auto_cost = None
+    if on_gpu and world == 1 and not a.no_auto_overhead and a.precision == HEADLINE:
+        # what a default-constructed model costs on top of this line's mode: precision="auto" = fp16x3 + the engine's error word read after
+        # every forward (one 4-byte D2H + stream sync per call), same K steps after the same warm-up, measured in this run
+        m_auto = make_model("auto")
+        dt_auto, q_auto, _ = run(m_auto, a.steps, a.warmup)
+        auto_cost = {"value": global_batch * a.steps / dt_auto, "ms_per_step": dt_auto / a.steps * 1e3, "overhead": dt_auto / dt - 1.0,
+                     "scores_identical_to_explicit_mode": bool(torch.equal(q_auto, q)), "engine_precision": m_auto.engine_precision}
+        del m_auto
+        torch.cuda.empty_cache()
     sustained = None
     if on_gpu and world == 1 and not a.no_sustained:
         n_s, dt_s, prof_s = run_sustained(model, a.sustained_seconds[0], a.sustained_seconds[1], profile_class=DOM)
@@ -610,7 +702,8 @@ def main():
         "collective_executed": bool(world > 1 or (collective or {}).get("collective_executed", False)),
         "collective": collective,
         # what a default-constructed model runs: precision="auto" = this line's fp16x3 + the error word read after every forward
-        "default_precision": "auto", "auto_overhead": 0.010, "auto_overhead_source": "profiles/r03_auto_cost.txt (B = 32, a caller that never synchronises)",
+        "default_precision": "auto", "auto_overhead": (auto_cost or {}).get("overhead"), "auto_overhead_measured_in_this_run": auto_cost,
+        "rank_devices": rank_devices,
         "rank_step_ms": {"min": min(headline_rank_times) / a.steps * 1e3, "max": max(headline_rank_times) / a.steps * 1e3},
         "allgather_us": allgather_us,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
@@ -646,10 +739,6 @@ def main():
                 "traffic": traffic * full_layers / per_step if traffic else None, "traffic_source": src,
                 # the numerics ceiling: bf16x3 issues 3 bf16 MFMAs per algorithmic product
                 "mode_cap": 1.0 / mpp, "frac_of_mode_cap": ach / PEAK_BF16_TFLOPS * mpp,
-                # what the matrix pipe sustains on all 256 CUs with register-only back-to-back MFMAs (tools/micro/mfma_peak.hip,
-                # profiles/r02_mfma_peak.txt, two boxes): the chip drops to 1.7-1.9 GHz under that load.  A committed measurement.
-                "matrix_pipe_sustained_tflops_measured": {"f16": [1801, 1923], "bf16": [1930, 2028], "e4m3": [4243, 4500],
-                                                          "source": "profiles/r02_mfma_peak.txt"},
                 "avg_launch_ms": ms_sum / launches, "launches": int(launches), "launches_per_step": per_step,
                 "flops_per_launch": flops_launch, "note": note}
 
@@ -663,8 +752,21 @@ def main():
     if prof and prof[1] > 0:
         out["roofline"] = roofline_of(prof, a.steps, "HIP events recorded by the engine on the launch stream around every fc1 launch "
                                       "of the timed region of `value`")
+        if on_gpu and world == 1 and not a.no_practical_peak:
+            # the denominator the performance argument rests on, measured on THIS box in THIS run: what a bare MFMA
+            # stream with this mode's operand bits sustains on all CUs; the dominant kernel's MFMA ISSUE rate (achieved x MFMAs per
+            # product) against it
+            pk = practical_peak(a.precision)
+            if pk:
+                rf = out["roofline"]
+                rf["practical_peak_tflops_measured_here"] = pk["operands_of_this_mode"]["tflops"]
+                rf["practical_peak"] = pk
+                rf["mfma_issue_tflops"] = rf["achieved"] * MFMA_PER_PRODUCT[a.precision]
+                rf["frac_of_practical"] = rf["mfma_issue_tflops"] / pk["operands_of_this_mode"]["tflops"]
+                rf["practical_peak_as_frac_of_nominal"] = pk["operands_of_this_mode"]["tflops"] / PEAK_BF16_TFLOPS
+                out["forward_frac_of_practical"] = out["forward_mfma_frac"] * PEAK_BF16_TFLOPS * MFMA_PER_PRODUCT[a.precision] / pk["operands_of_this_mode"]["tflops"]
     q_other = {}
-    if not a.no_second_mode:                     # every rank: run() is collective
+    if not a.no_second_mode and (world == 1 or a.other_modes_multi_gpu):      # every rank: run() is collective; N > 1: the headline mode only by default
         del model
         torch.cuda.empty_cache()
         out["other_modes"] = {}
@@ -720,6 +822,35 @@ def main():
                             "flops_per_pair": spec2.flops_per_pair(N2), "flops_per_pair_executed": f2, "seq_len": spec2.seq_len(N2)}
         del m2
         torch.cuda.empty_cache()
+    if not a.no_latency and world == 1 and on_gpu:
+        out["latency"] = {"numerics": a.precision, "patches": N, "workload": "ViT-B/16 (L=12, T=1) FR pair forward at B pairs per forward",
+                          "rows": latency_block(torch, make_model, a.precision, device, N)}
+        kwl = dict(vit_config=dict(variant="ViT-B16", pretrained=False, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True), ca_reduction=16)
+
+        def make_refdefault(precision):
+            ml = VTAMIQ(**json.loads(json.dumps(kwl)), precision=precision)
+            ml.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(ml.spec, 0).items()})
+            return ml.to(device).eval()
+        out["latency"]["reference_default_topology"] = {"workload": "L=6, T=9, LayerScale, r=16 (train_config.py:169-194), 512 patches",
+                                                        "rows": latency_block(torch, make_refdefault, a.precision, device, 512, batches=(1, 16))}
+    # N > 1: scaling against the committed N = 1 line of this tree's bench.py (the driver computes its own efficiency from its own runs)
+    if world > 1 and rank == 0:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")), reverse=True):
+            try:
+                n1 = json.load(open(path))
+                if n1.get("n_gpus") == 1 and n1.get("config", {}).get("numerics") == a.precision and n1.get("config", {}).get("patches") == N:
+                    out["scaling_efficiency_vs_committed_n1"] = {"value": pairs_per_s / (world * n1["value"]), "n1_value": n1["value"],
+                                                                 "n1_source": "profiles/" + os.path.basename(path)}
+                    break
+            except Exception:
+                continue
+    # (c) nothing rank-0-only between collectives: the process group is closed BEFORE rank 0's host-side work (oracle parity check, CPU
+    # baseline, fidelity, PMC passes), so the other ranks never spin in an RCCL barrier while rank 0 computes on the host
+    if world > 1:
+        dist.barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
     if rank == 0:
         # parity of both modes on the first pairs of rank 0's shard, against the oracle on the host (not timed)
         from oracle import vtamiq_oracle as O
@@ -764,10 +895,6 @@ def main():
             else:
                 out["roofline"]["traffic_live_error"] = src
         print(json.dumps(out), file=real_stdout, flush=True)
-    if world > 1:
-        dist.barrier()
-    if dist.is_initialized():
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

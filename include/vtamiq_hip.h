@@ -175,6 +175,13 @@ int  vtq_k_gemm_tile_rule(int32_t M, int32_t N, int32_t K, int32_t num);
  * device with `cus` compute units: 2 = split, 1 = pipelined, 0 = 4-wave, -1 = bad format code. */
 int  vtq_k_attention_rule(int32_t nseq, int32_t S_pad, int32_t H, int32_t num, int32_t cus);
 
+/* The practical ceiling of the matrix pipe on this device (csrc/mfma_stream.hip; bench.py roofline.practical_peak_tflops_measured_here): a bare
+ * stream of back-to-back mfma_f32_16x16x32 on register operands on every CU for >= timed_s seconds after >= warm_s seconds of the same
+ * load (each <= 30).  f16: 0 = bf16, 1 = fp16 operands; data: 0 = the operand bits of a 3-term product (hi x hi, hi x lo, lo x hi of
+ * gaussian planes), 1 = zeros (the issue limit), 2 = uniform random.  *tflops = MFMA-issue TFLOP/s, *ghz (may be NULL) = the clock it
+ * implies.  Blocks the calling thread; measurement only. */
+int  vtq_debug_mfma_stream(int32_t f16, int32_t data, double warm_s, double timed_s, double* tflops, double* ghz, void* stream);
+
 /* ---- measurement: per-kernel-class HIP-event timing on the launch stream ------------------------------ */
 #define VTQ_K_CONVERT  0
 #define VTQ_K_PATCH    1   /* patch-embedding GEMM + pos/scale gather epilogue */

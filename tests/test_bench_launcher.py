@@ -40,6 +40,20 @@ def test_self_launch_two_gloo_ranks():
     assert abs(d["q_checksum"] - _expected_checksum(2, 3, 5)) < 1e-4
 
 
+def test_self_launch_eight_gloo_ranks():
+    """The driver's 8-GPU run, dry: 8 ranks started by the parent, one JSON line, every rank's shard through the
+    all-gather in rank order, 8 distinct 'devices' reported and checked before timing, per-rank step times on the line."""
+    p = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "5", "--patches", "4", "--backend", "gloo", "--stub"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["global_batch"] == 40 and d["config"]["parallelism"] == "dp8"
+    assert abs(d["q_checksum"] - _expected_checksum(8, 5, 4)) < 1e-4
+    assert [r["rank"] for r in d["rank_devices"]] == list(range(8)) and len({r["pci_bus_id"] for r in d["rank_devices"]}) == 8
+    assert 0 < d["rank_step_ms"]["min"] <= d["rank_step_ms"]["max"]
+
+
 def test_single_rank_needs_no_launcher():
     p = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--patches", "4", "--backend", "gloo", "--stub"])
     assert p.returncode == 0, p.stderr[-2000:]

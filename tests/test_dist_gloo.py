@@ -52,6 +52,40 @@ def test_two_rank_shard_and_gather(tmp_path, global_batch):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
 
 
+def _worker8(rank, world, port, global_batch, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.bench_stub import StubModel
+    from vtamiq_amd.dist import shard_range, sharded_forward
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(5)
+    ref = torch.rand(global_batch, 3, 3, 4, 4, generator=g)
+    dst = torch.rand(global_batch, 3, 3, 4, 4, generator=g)
+    pos = torch.rand(global_batch, 3, 2, generator=g)
+    lo, hi = shard_range(global_batch, rank, world)
+    qg = sharded_forward(StubModel(), (ref[lo:hi], dst[lo:hi]), (pos[lo:hi], pos[lo:hi]), (None, None), global_batch)
+    if rank in (0, world - 1):
+        np.save(os.path.join(out_dir, f"q{rank}.npy"), qg.numpy())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "want.npy"), StubModel()((ref, dst), (pos, pos), (None, None))[0].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [256, 257])
+def test_eight_rank_shard_and_gather(tmp_path, global_batch):
+    """BASELINE configs[2] in shape: a global batch over 8 ranks, even (256 = 8 x 32) and uneven (257: rank 0 owns one pair more and the
+    other ranks' shards are padded inside the fixed-size all-gather); every rank ends with all scores in global pair order."""
+    world = 8
+    mp.spawn(_worker8, args=(world, 29300 + (os.getpid() % 200) + global_batch % 7, global_batch, str(tmp_path)), nprocs=world, join=True)
+    want = np.load(os.path.join(str(tmp_path), "want.npy"))
+    for r in (0, world - 1):
+        got = np.load(os.path.join(str(tmp_path), f"q{r}.npy"))
+        assert got.shape == (global_batch,)
+        np.testing.assert_array_equal(got, want)
+
+
 def test_shard_ranges_cover():
     from vtamiq_amd.dist import shard_range
     for gb in (1, 7, 8, 256, 257):

@@ -137,7 +137,7 @@ def test_attention_kernel_rule():
     assert rule(64, 501, 768, "fp16") == 0 and rule(64, 501, 768, "bf16") == 0              # single-plane formats: 4-wave kernel
     assert rule(32, 1025, 1024, "fp16x3") == 2                                              # configs[3]: the one row of the 5th block goes to the split form
     assert rule(8, 2501, 768, "fp16x3") == 1                                                # N = 2500: 960 blocks = 3.75 per CU
-    assert rule(2, 257, 768, "fp16x3") == 0 and rule(64, 300, 768, "fp16x3") == 0           # 33 % more padded rows
+    assert rule(2, 257, 768, "fp16x3") == 0 and rule(64, 330, 768, "fp16x3") == 0           # 33 % more padded rows
     assert rule(4, 300, 768, "fp16x3") == 0 and rule(3, 51, 768, "fp16x3") == 0             # grids that leave CUs idle
     assert rule(8, 501, 768, "fp16x3") == 0 and rule(10, 501, 768, "fp16x3") == 1           # 192 / 240 blocks of 256 slots
     assert rule(14, 501, 768, "fp16x3") == 0 and rule(19, 501, 768, "fp16x3") == 1          # 336 of 512 slots: 66 %; 456: 89 %

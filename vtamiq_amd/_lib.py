@@ -59,6 +59,7 @@ SIGNATURES = {
     "vtq_k_attention_rule": (C.c_int, [C.c_int32] * 5),
     "vtq_debug_gemm_variant": (C.c_int, [C.c_int32]),
     "vtq_k_gemm_tile_rule": (C.c_int, [C.c_int32] * 4),
+    "vtq_debug_mfma_stream": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

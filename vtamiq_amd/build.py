@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libvtamiq_hip.so")
-SOURCES = ["gemm.hip", "gemm_st.hip", "gemm_rowln.hip", "attention.hip", "elementwise.hip", "head.hip", "skinny.hip", "cls_tail.hip", "patches.hip", "metrics.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm_st.hip", "gemm_rowln.hip", "attention.hip", "elementwise.hip", "head.hip", "skinny.hip", "cls_tail.hip", "patches.hip", "metrics.hip", "mfma_stream.hip", "engine.hip"]
 DEPS = ["dev_common.h", "kernels.h", os.path.join("..", "..", "include", "vtamiq_hip.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (no v_accvgpr_read/write shuffles around the softmax)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -871,6 +871,13 @@ int vtq_debug_gemm_diag(void* buf, int32_t shadow) {
     return gemm_is_diag_build() ? 1 : 0;
 }
 
+int vtq_debug_mfma_stream(int32_t f16, int32_t data, double warm_s, double timed_s, double* tflops, double* ghz, void* stream) {
+    if (f16 < 0 || f16 > 1 || data < 0 || data > 2 || !(warm_s >= 0.0) || !(timed_s > 0.0) || warm_s > 30.0 || timed_s > 30.0 || !tflops)
+        return fail("vtq_debug_mfma_stream: bad argument");
+    HIP_TRY(mfma_stream_measure(f16, data, warm_s, timed_s, tflops, ghz, (hipStream_t)stream));
+    return 0;
+}
+
 int vtq_profile_enable(vtq_handle e, uint32_t mask) {
     if (!e) return fail("null handle");
     e->prof_mask = mask;

@@ -208,6 +208,10 @@ hipError_t launch_avgpool2(const float* in, float* out, int NC, int H, int W, hi
 hipError_t launch_gather_patches(const float* const* levels, const int* hs, const int* ws, int nlevels, const int* samples,
                                  const int* scale_ids, float* patches, float* pos, float* scales, int NI, int N, hipStream_t s, int P = 16);
 
+// ---- measurement: the matrix pipe's sustained rate on this device (mfma_stream.hip) -----------------------------------------
+// f16: 0 bf16, 1 fp16 operands; data: 0 the 3-term mix of gaussian hi / lo planes, 1 zeros, 2 uniform random
+hipError_t mfma_stream_measure(int f16, int data, double warm_s, double timed_s, double* tflops, double* ghz, hipStream_t s);
+
 // ---- validation reductions (metrics.hip) --------------------------------------------------------------------------------
 hipError_t launch_repeat_mean(const float* q, double* out, int R, int N, hipStream_t s);
 hipError_t launch_rank_metrics(const double* a, const double* b, int N, int normalize, double* aa, double* bb, double* ra, double* rb,
