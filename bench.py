@@ -31,7 +31,8 @@ PEAK_BF16_TFLOPS = 2516.6        # dense bf16 MFMA: 256 CU x 4096 flop/clk/CU x 
 # fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents (its cap is 2x the bf16 roofline)
 MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0, "fp16": 1.0, "fp16x2": 2.0, "fp16x3": 3.0, "fp8": 0.5}
 HEADLINE = "fp16x3"          # default `value` mode; OTHER_MODES are timed beside it
-OTHER_MODES = ("fp16x2", "fp16", "fp8")
+OTHER_MODES = ("fp16x2", "fp16", "fp8")   # fp8: only when the loaded library is a build of the fp8 EXPERIMENT (python -m vtamiq_amd.build --fp8,
+                                          # VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so); the product library does not have the mode
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -611,14 +612,23 @@ def main():
             dist.destroy_process_group()
         return
 
-    from vtamiq_amd import VTAMIQ, synth
+    from vtamiq_amd import VTAMIQ, synth, _lib as _vlib
+    fp8_ok = bool(on_gpu and _vlib.has_fp8())
+    if a.precision == "fp8" and not fp8_ok:
+        sys.exit("bench.py --precision fp8: the loaded library has no fp8 experiment (python -m vtamiq_amd.build --fp8; VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so)")
+
+    def model_class(precision):
+        if precision != "fp8":
+            return VTAMIQ
+        from vtamiq_amd.experimental_fp8 import VTAMIQFp8
+        return VTAMIQFp8
     kw = dict(vit_config=dict(variant="ViT-B16", pretrained=False))   # L=12, T=1, r=8: BASELINE configs 2/3 and north star; seeded weights
-    spec = VTAMIQ(**json.loads(json.dumps(kw)), precision=a.precision).spec
+    spec = model_class(a.precision)(**json.loads(json.dumps(kw)), precision=a.precision).spec
     sd_np = synth.make_state_dict(spec, 0)
     state = {k: torch.from_numpy(v) for k, v in sd_np.items()}
 
     def make_model(precision):
-        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=precision)
+        m = model_class(precision)(**json.loads(json.dumps(kw)), precision=precision)
         m.load_state_dict(state)
         return m.to(device).eval()
 
@@ -689,7 +699,7 @@ def main():
     f_exec = f_exec_of(a.precision)
     S = spec.seq_len(N)
     mfma_frac = lambda pps, prec=a.precision: pps / world * f_exec_of(prec) / (PEAK_BF16_TFLOPS * 1e12)
-    others = [m for m in OTHER_MODES if m != a.precision]
+    others = [m for m in OTHER_MODES if m != a.precision and (m != "fp8" or fp8_ok)]
 
     out = {
         "metric": "image-pairs/sec ViT-B/16 P=500 patches, 1->8 MI355X; % bf16 MFMA roofline",
@@ -704,6 +714,7 @@ def main():
         # what a default-constructed model runs: precision="auto" = this line's fp16x3 + the error word read after every forward
         "default_precision": "auto", "auto_overhead": (auto_cost or {}).get("overhead"), "auto_overhead_measured_in_this_run": auto_cost,
         "rank_devices": rank_devices,
+        "fp8_experiment_in_this_library": fp8_ok,
         "rank_step_ms": {"min": min(headline_rank_times) / a.steps * 1e3, "max": max(headline_rank_times) / a.steps * 1e3},
         "allgather_us": allgather_us,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "
@@ -807,7 +818,7 @@ def main():
         # SURVEY 8(d) secondary row: the reference-default topology -- what the released checkpoint runs (train_config.py:169-194,
         # 356-369: 6 kept layers, 8 register tokens, LayerScale, ca_reduction 16) at B = 16, N = 512
         kw2 = dict(vit_config=dict(variant="ViT-B16", pretrained=False, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True), ca_reduction=16)
-        m2 = VTAMIQ(**json.loads(json.dumps(kw2)), precision=a.precision)
+        m2 = model_class(a.precision)(**json.loads(json.dumps(kw2)), precision=a.precision)
         spec2 = m2.spec
         m2.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec2, 0).items()})
         m2 = m2.to(device).eval()
@@ -828,7 +839,7 @@ def main():
         kwl = dict(vit_config=dict(variant="ViT-B16", pretrained=False, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True), ca_reduction=16)
 
         def make_refdefault(precision):
-            ml = VTAMIQ(**json.loads(json.dumps(kwl)), precision=precision)
+            ml = model_class(precision)(**json.loads(json.dumps(kwl)), precision=precision)
             ml.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(ml.spec, 0).items()})
             return ml.to(device).eval()
         out["latency"]["reference_default_topology"] = {"workload": "L=6, T=9, LayerScale, r=16 (train_config.py:169-194), 512 patches",
@@ -875,7 +886,7 @@ def main():
         if not a.no_fidelity and world == 1 and on_gpu:
             # every mode's scores against the fp32 oracle in the reference's own metric (bounded sample; the full table on flat-init
             # and trained-like weights is profiles/r03_mode_fidelity.txt, tools/mode_fidelity.py)
-            out["fidelity"] = mode_fidelity(torch, make_model, spec, sd_np, ["fp16x3", "bf16x3", "fp16x2", "fp16", "bf16", "fp8"], device,
+            out["fidelity"] = mode_fidelity(torch, make_model, spec, sd_np, ["fp16x3", "bf16x3", "fp16x2", "fp16", "bf16"] + (["fp8"] if fp8_ok else []), device,
                                             pairs=a.fidelity_pairs, N=N, threads=min(effective_cores(), 64))
         if "roofline" in out and world == 1 and not a.no_live_traffic:
             # HBM-side bytes of the dominant kernel measured on THIS box now (the timed regions are over; the GPU is idle)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 5
+#define VTQ_ABI_VERSION 6
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -34,10 +34,8 @@ extern "C" {
 #define VTQ_PREC_FP16X3 3   /* operands split hi+lo fp16, 3 MFMAs per product: at the fp32 reference's own noise floor         */
 #define VTQ_PREC_FP16X2 4   /* linear layers: activations split hi+lo fp16, weights single fp16 (2 MFMAs per product);         */
                             /* attention (QK^T, PV): the 3-term fp16 form                                                      */
-#define VTQ_PREC_FP8    5   /* BASELINE configs[4]: linear layers on OCP e4m3 operands with the MX-scaled MFMA (unit block      */
-                            /* scales, 2x the bf16 MFMA rate): weights e4m3 with per-output-channel power-of-two scales,         */
-                            /* activations e4m3 with calibrated per-tensor scales (vtq_fp8_*); attention single fp16; head hi/lo.  */
-                            /* Checked against the fake-quant oracle (oracle/fp8_oracle.py), NOT within 1e-3 of the fp32 model. */
+/* 5 is the fp8 EXPERIMENT (BASELINE configs[4]): not a scoring mode and not in this library -- vtq_create rejects it unless the library
+ * was built with -DVTQ_WITH_FP8; its constants and entry points live in include/vtamiq_hip_fp8.h. */
 
 /* operand-format code of the per-kernel entry points: MFMAs per product (1 | 2 | 3) + 16 for fp16 planes (0 = bf16):
  *   1 / 17 single plane each; 18 = activation hi/lo planes x single weight plane (fp16 only); 3 / 19 = hi/lo planes for both */
@@ -46,7 +44,6 @@ extern "C" {
 #define VTQ_NUM_FP16   17
 #define VTQ_NUM_FP16X2 18
 #define VTQ_NUM_FP16X3 19
-#define VTQ_NUM_FP8    33   /* e4m3 bytes, one plane each (vtq_k_gemm_fp8) */
 
 typedef struct vtq_config {
     int32_t hidden_size;       /* 768 | 1024                (transformer.py:68-98)                    */
@@ -72,7 +69,7 @@ typedef struct vtq_config {
 /* vtq_config.options.  The library reads NO environment variable: what rounds 1-3 steered through VTQ_NO_CLS_PRUNE /
  * VTQ_FP8_STATIC_SCALES is an explicit field of the configuration the caller hands over. */
 #define VTQ_OPT_FULL_LAST_LAYER   1   /* run the last encoder layer on every token row instead of on the CLS rows only (same result) */
-#define VTQ_OPT_FP8_STATIC_SCALES 2   /* VTQ_PREC_FP8: keep the static default activation scales, never calibrate                    */
+                                      /* (2 belongs to the fp8 experiment: include/vtamiq_hip_fp8.h)                                  */
 #define VTQ_OPT_FUSED_LAYERNORM   4   /* LayerNorm inside the residual GEMMs: the out-proj launch also writes LayerNorm 2's operand planes, */
                                       /* the fc2 launch the next layer's LayerNorm 1 planes (csrc/gemm_rowln.hip; hidden 768, 3-term          */
                                       /* formats, no adapters: vtq_create fails otherwise).  Bit-identical scores; measured 1.3 % SLOWER at   */
@@ -124,24 +121,9 @@ int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float
  * (transformer.py:417-421); vtq_forward clamps such an index into the table instead of gathering out of bounds and records it.
  * Bit 1: the CLS difference of some pair was not finite -- an operand left its format's range upstream (the fp16 operand modes
  * carry |v| <= 65504; VTQ_PREC_BF16X3 has the fp32 range), or the inputs / weights held inf / NaN.
- * Bit 2 (VTQ_PREC_FP8): an activation times its scale exceeded e4m3's largest value and was clamped to +-448 (the scales no
- * longer fit the data: calibrate again, vtq_fp8_calibrate).
+ * (Bit 2 is raised by the fp8 experiment only: include/vtamiq_hip_fp8.h.)
  * This call synchronises `stream`, returns the flags accumulated since the last call and clears them. */
 int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
-
-/* VTQ_PREC_FP8: per-tensor power-of-two activation scales, one per quantisation point -- [0] the packed patches, then for every
- * layer l: [1 + 4l] LayerNorm-1 output, [2 + 4l] attention context, [3 + 4l] LayerNorm-2 output, [4 + 4l] GELU output.
- * An engine starts with static defaults (256, 8, 16, 8, 4) and CALIBRATES on the batch of its first vtq_forward: every producing
- * kernel reports max |value|, the largest power of two mapping it to <= 224 becomes the scale, the producer is run again with
- * it (one stream synchronisation per point, that forward only; its scores are computed with the final scales).  vtq_config.options
- * & VTQ_OPT_FP8_STATIC_SCALES keeps the defaults.  vtq_load_weights marks the engine uncalibrated again (scales fitted to other
- * weights would clamp) unless the current scales were installed through vtq_fp8_set_scales.  vtq_fp8_calibrate repeats the calibration on a batch of the caller's choice
- * (arguments as vtq_forward); get / set expose the 1 + 4 * num_layers values (get returns the count, -1 for a non-fp8 engine;
- * set requires positive powers of two and marks the engine calibrated). */
-int  vtq_fp8_calibrate(vtq_handle h, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
-                       const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream);
-int  vtq_fp8_get_scales(vtq_handle h, float* out, int32_t cap);
-int  vtq_fp8_set_scales(vtq_handle h, const float* scales, int32_t n);
 
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors
@@ -221,17 +203,6 @@ int  vtq_k_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int6
 int  vtq_k_gemm_rowln(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t K, int32_t num,
                       const float* bias, const float* gamma, float* x_f32, const float* ln_w, const float* ln_b,
                       void* out16, int64_t o_plane, void* stream);
-
-/* fp8 (VTQ_PREC_FP8) building blocks.  vtq_k_quant_rows_fp8: W[N][K] fp32 -> e4m3 rows, each scaled by the largest power of two
- * that keeps its maximum <= 448, inv_scale[n] = 1 / scale.  vtq_k_quant_fp8: e4m3(src * scale), clamped to +-448.
- * vtq_k_gemm_fp8: C = A8[M,K] * W8[N,K]^T on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), acc * wscale[n] * ascale_inv,
- * then the epilogue: 0 -> out = fp16 (one plane) of (v + bias); 1 -> out = e4m3(gelu(v + bias) * out_scale), ldo bytes per row;
- * 2 -> x_f32 += gamma * (v + bias).  M%256==0, N%256==0, K%256==0. */
-int  vtq_k_quant_rows_fp8(const float* W, void* dst, float* inv_scale, int32_t N, int32_t K, void* stream);
-int  vtq_k_quant_fp8(const float* src, void* dst, int64_t numel, float scale, void* stream);
-int  vtq_k_gemm_fp8(const void* A8, int32_t lda, const void* W8, const float* wscale, float ascale_inv, int32_t M, int32_t N, int32_t K,
-                    int32_t epilogue, const float* bias, const float* gamma, float* x_f32, void* out, int64_t o_plane, int32_t ldo,
-                    float out_scale, void* stream);
 
 /* HOST-only: the persistent schedule vtq_k_gemm uses for an [M, N] output (M, N multiples of 256) with K columns and `wplanes`
  * weight planes: out[0..256] = begin offsets of the 256 workgroups' lists (out[256] = total length), then the lists:

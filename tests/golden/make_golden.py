@@ -87,12 +87,13 @@ def build_reference(vtamiq_kwargs):
     return model
 
 
-def seeded_state(spec, seed, stress_qk=None):
-    """numpy state dict: the flat random init, or (stress_qk) tests.helpers.stress_state's trained-like statistics."""
+def seeded_state(spec, seed, stress_qk=None, stress_head=False):
+    """numpy state dict: the flat random init, or (stress_qk) tests.helpers.stress_state's trained-like statistics (stress_head: with the
+    head at a trained model's operating point)."""
     if stress_qk is None:
         return synth.make_state_dict(spec, seed)
     from tests.helpers import stress_state
-    return stress_state(spec, seed, qk=float(stress_qk))
+    return stress_state(spec, seed, qk=float(stress_qk), head=stress_head)
 
 
 def load_seeded(model, spec, seed, stress_qk=None):
@@ -332,7 +333,7 @@ def run_validation_metrics():
     np.savez(os.path.join(HERE, "validation_metrics.npz"), **out)
 
 
-def run_ladder_case(name, vtamiq_kwargs, images, N, wseed, iseed, stress_qk, chunk=8):
+def run_ladder_case(name, vtamiq_kwargs, images, N, wseed, iseed, stress_qk, chunk=8, stress_head=False):
     """SCORES ONLY, at the BASELINE patch count: the reference in fp32 and in float64 on stress_state weights over a distortion
     ladder of images * 8 pairs (synth.make_ladder_inputs) -- the trained-like parity tail pinned by the reference itself at
     N = 500.  Run in chunks of `chunk` pairs (the reference materialises every attention matrix)."""
@@ -341,8 +342,9 @@ def run_ladder_case(name, vtamiq_kwargs, images, N, wseed, iseed, stress_qk, chu
     patches, pos, scales = synth.make_ladder_inputs(spec, images, N, iseed)
     assert scales is None
     B = patches.shape[0]
-    sdnp = seeded_state(spec, wseed, stress_qk)
-    out = dict(kwargs=json.dumps(vtamiq_kwargs), images=images, B=B, N=N, wseed=wseed, iseed=iseed, stress_qk=np.float64(stress_qk))
+    sdnp = seeded_state(spec, wseed, stress_qk, stress_head)
+    out = dict(kwargs=json.dumps(vtamiq_kwargs), images=images, B=B, N=N, wseed=wseed, iseed=iseed, stress_qk=np.float64(stress_qk),
+               stress_head=int(stress_head))
     for tag, dt in (("q", torch.float32), ("q64", torch.float64)):
         model = build_reference(kw).to(dt)
         model.load_state_dict({k: torch.from_numpy(v).to(dt) for k, v in sdnp.items()}, strict=True)
@@ -383,6 +385,13 @@ def run_ladder():
     run_ladder_case("stress5_b64_n500", dict(vit_config=dict(variant="ViT-B16")), images=8, N=500, wseed=32, iseed=777, stress_qk=5.0)
 
 
+def run_operating_point():
+    """The 64-pair N = 500 ladder through a head at a trained model's operating point (tests.helpers.stress_state(head=True): scores in
+    [0.2, 0.8] instead of cancellation remainders around zero), scored by the reference in fp32 and float64 (round 5; ~10 min of CPU)."""
+    run_ladder_case("stress5h_b64_n500", dict(vit_config=dict(variant="ViT-B16")), images=8, N=500, wseed=32, iseed=777, stress_qk=5.0,
+                    stress_head=True)
+
+
 def run_stress():
     """The reference itself on weights with trained-ViT-like statistics (tests.helpers.stress_state: peaked softmax, outlier
     channels) -- the flat random init of the other cases exercises none of that (transformer.py:153-172)."""
@@ -414,6 +423,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--ladder":         # only the 64-pair N = 500 trained-like case (added in round 4; ~10 min)
         run_ladder()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--operating-point":   # only the operating-point ladder (added in round 5; ~10 min)
+        run_operating_point()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--stress":         # only the trained-like-statistics cases (added in round 3)
         run_stress()
         return
@@ -436,6 +448,7 @@ def main():
              B=2, N=40, wseed=22, iseed=19)
     run_stress()
     run_ladder()
+    run_operating_point()
     run_fullsize()
     run_fullsize_c4()
     run_ops()

@@ -36,6 +36,8 @@ def load_case(name):
 FULLSIZE_CASES = ["c2_b32_n500", "refdefault_b16_n512", "c4_vitl_b16_n1024"]     # the last: BASELINE configs[3] whole (ViT-L/16, 3 scales)
 
 LADDER_CASES = ["stress5_b64_n500"]       # 64 pairs at the BASELINE patch count on trained-like weights: scores only (fp32 + float64)
+# the same ladder through a head at a trained model's operating point (stress_state(head=True)): scores in [0.2, 0.8]
+OPERATING_POINT_CASES = ["stress5h_b64_n500"]
 
 
 def load_ladder_case(name):
@@ -44,7 +46,7 @@ def load_ladder_case(name):
     kw = json.loads(str(g["kwargs"]))
     kw.setdefault("vit_config", {})["pretrained"] = False
     spec = make_spec(**json.loads(json.dumps(kw)))
-    sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"]))
+    sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"]), head=bool(int(g.get("stress_head", 0))))
     patches, pos, scales = synth.make_ladder_inputs(spec, int(g["images"]), int(g["N"]), int(g["iseed"]))
     assert patches.shape[0] == int(g["B"])
     assert abs(float(patches.astype(np.float64).sum()) - float(g["fp_patches"])) < 1e-6
@@ -87,10 +89,13 @@ def gate_error(q, q_ref, floor=0.1):
     return float(np.max(np.abs(q - q_ref) / den))
 
 
-def stress_state(spec, seed, qk=3.0, mlp=3.0, outlier=8.0):
+def stress_state(spec, seed, qk=3.0, mlp=3.0, outlier=8.0, head=False):
     """Seeded weights with trained-ViT-like statistics instead of the flat random init: query/key scaled so the softmax is
     peaked (mean max-probability 0.5 .. 0.95 instead of 1/S), larger value / MLP gains, and four 'massive activation' channels
-    per layer (LayerNorm gains x8, fc2 bias +2) so the residual stream carries outliers of ~30x its rms."""
+    per layer (LayerNorm gains x8, fc2 bias +2) so the residual stream carries outliers of ~30x its rms.
+    head=True: also a head at a trained model's OPERATING POINT -- the released checkpoint predicts normalised MOS of O(0.1 .. 1)
+    (data/patch_datasets.py:51-52), not the near-zero cancellation remainders of a random head: q_predictor.4.bias = 0.4 and gains of
+    1.5 on the RCAB convs and the predictor's first layer (0.9 on its last) put the 64 scores of the N = 500 ladder in [0.27, 0.78]."""
     from vtamiq_amd import synth
     sd = synth.make_state_dict(spec, seed)
     rs = np.random.default_rng(seed)
@@ -106,4 +111,11 @@ def stress_state(spec, seed, qk=3.0, mlp=3.0, outlier=8.0):
         sd[p + "attention_norm.weight"][ch] *= outlier
         sd[p + "ffn_norm.weight"][ch] *= outlier
         sd[p + "ffn.fc2.bias"][ch] += 2.0
+    if head:
+        for k in sd:
+            if k.startswith("quality_decoder.") and k.endswith("body.2.weight"):
+                sd[k] *= 1.5
+        sd["q_predictor.1.weight"] *= 1.5
+        sd["q_predictor.4.weight"] *= 0.9
+        sd["q_predictor.4.bias"][:] = 0.4
     return sd

@@ -1,4 +1,4 @@
-"""The fp8 numerics mode (include/vtamiq_hip.h VTQ_PREC_FP8; BASELINE.json configs[4]) on the GPU, through the C ABI:
+"""The fp8 EXPERIMENT (include/vtamiq_hip_fp8.h VTQ_PREC_FP8, vtamiq_amd/experimental_fp8.py; BASELINE.json configs[4]) on the GPU, through the C ABI:
   * the e4m3 rounding of weights and activations is BIT-exact against the fake-quant oracle's rules (oracle/fp8_oracle.py);
   * the MX-scaled-MFMA GEMM reproduces the exact products of the operand bytes (fp64 reference) with each of its epilogues;
   * the engine computes the fp8 MODEL the oracle defines: stage by stage on the engine's own stage inputs (the only form in which
@@ -17,9 +17,19 @@ from oracle import fp8_oracle as F8
 from oracle import vtamiq_oracle as O
 from tests.gpu_util import planes_value, stream
 from tests.helpers import E2E_CASES, gate_error, load_case, split_inputs
-from vtamiq_amd import VTAMIQ, _lib
+from vtamiq_amd import _lib
+from vtamiq_amd.experimental_fp8 import VTAMIQFp8 as VTAMIQ
 
-pytestmark = pytest.mark.gpu
+def _has_fp8():
+    try:
+        return _lib.has_fp8()
+    except Exception:
+        return False
+
+
+# The fp8 EXPERIMENT is not in the product library: these tests run on a build of it only,
+#   python -m vtamiq_amd.build --fp8 && VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so python -m pytest tests/test_gpu_fp8.py -m gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _has_fp8(), reason="library built without the fp8 experiment (python -m vtamiq_amd.build --fp8; VTQ_LIB_PATH)")]
 DEV = "cuda"
 
 
@@ -416,3 +426,65 @@ def test_fp8_pairwise_triplets_match_two_calls():
         q2 = m((pr, pd2), (qr, qd1), (sr, sd1))[0]
         f1, f2 = m.forward_pairwise((pr, pd1, pd2), (qr, qd1, qd1), (sr, sd1, sd1))
     assert torch.equal(f1, q1) and torch.equal(f2, q2) and bool(torch.isfinite(f1).all())
+
+
+def test_fp8_repeated_forwards_are_bitwise_identical():
+    """(moved here from test_gpu_parity.py with the mode) the same batch 25 times, interleaved with another batch: identical bits."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c2shape_b4_n500")
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to("cuda").eval()
+    p, ps, sc = split_inputs(patches, pos, scales, device="cuda")
+    other = tuple(t.flip(0).contiguous() for t in p)
+    with torch.no_grad():
+        q0 = m(p, ps, sc)[0].clone()
+        for i in range(25):
+            if i % 3 == 0:
+                m(other, ps, sc)
+            assert torch.equal(m(p, ps, sc)[0], q0), i
+
+
+def test_fp8_auto_scales_never_outlive_the_weights_they_fit():
+    """auto-calibrated scales belong to one (engine, weights) pair.  forward -> .to() (same device: weights re-packed) ->
+    forward -> load_state_dict of 8x larger weights -> forward: the scales CHANGE (they were fitted to the old activations), the saved
+    copy follows, and no stale set is ever re-installed; user-installed scales survive the same sequence."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    p, ps, sc = split_inputs(patches, pos, scales, device="cuda")
+    state = {k: torch.from_numpy(v) for k, v in sd.items()}
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+    m.load_state_dict(state)
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        m(p, ps, sc)
+        s0 = m.fp8_scales()
+        m = m.to("cuda")                                   # re-pack: the engine recalibrates on the next forward, the saved copy is dropped
+        assert m.__dict__.get("_fp8_saved") is None or m._weights_sig is None
+        m(p, ps, sc)
+        assert m.fp8_scales() == s0                        # same weights, same batch: the same scales again
+        big = {k: (v * 8.0 if k.endswith("ffn.fc1.weight") or k.endswith("attention_norm.weight") else v) for k, v in state.items()}
+        m.load_state_dict(big)
+        m(p, ps, sc)
+        s1 = m.fp8_scales()
+        assert s1 != s0 and m.__dict__["_fp8_saved"] == s1
+        assert all(a <= b for a, b in zip(s1["ln1"], s0["ln1"])) and s1["ln1"] != s0["ln1"]      # larger activations: smaller scales
+        m.set_fp8_scales(s0)                               # the user's scales: kept across a reload
+        m.load_state_dict(state)
+        m(p, ps, sc)
+        assert m.fp8_scales() == s0
+
+
+def test_fp8_validate_inputs_raises_after_every_forward():
+    """precision fp8 with validate_inputs keeps the documented contract -- IndexError for a position outside [0, 1)."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("c1_b2_n50")
+    m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to("cuda").eval()
+    m.validate_inputs = True
+    p, ps, sc = split_inputs(patches, pos, scales, device="cuda")
+    with torch.no_grad():
+        m(p, ps, sc)
+        bad = (ps[0].clone(), ps[1].clone())
+        bad[1][0, 3, 0] = 1.5
+        with pytest.raises(IndexError):
+            m(p, bad, sc)
+        m(p, ps, sc)                                       # the flag was consumed: a clean batch passes again

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, STRESS_CASES, gate_error, load_case, load_ladder_case, rel_err, split_inputs, stress_state
+from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, OPERATING_POINT_CASES, STRESS_CASES, gate_error, load_case, load_ladder_case, rel_err, split_inputs, stress_state
 from vtamiq_amd import VTAMIQ, _lib, synth
 from vtamiq_amd.predict import get_data_tuple, predict
 
@@ -129,6 +129,36 @@ def test_golden_trained_like_ladder_at_baseline_patch_count(name):
         print(f"\n[{name} {MAIN}] vs reference {'fp32' if tag == 'q' else 'fp64'}: gate {ge:.2e}; raw max over |q| >= 0.1 rms {raw[big].max():.2e}, "
               f"p95 {np.percentile(raw, 95):.2e}, raw max over all {raw.max():.2e} (|q| = {abs(ref[np.argmax(raw)]):.1e})")
         assert ge < 1e-3, (tag, ge)
+
+
+@pytest.mark.parametrize("name", OPERATING_POINT_CASES)
+def test_golden_at_a_trained_models_operating_point(name):
+    """The 64-pair N = 500 ladder on stress_state(qk = 5) weights through a head at a trained model's OPERATING POINT (scores in [0.2, 0.8],
+    std 0.1: the released checkpoint predicts normalised MOS of that order, data/patch_datasets.py:51-52; every other reference-pinned case
+    has scores that are cancellation remainders around zero), scored by the REFERENCE in fp32 and float64 (make_golden.py --operating-point).
+    Gate for the parity mode: 1e-3 RAW relative on EVERY score, no rms floor.  The other modes are printed with the same measure and
+    gated loosely: here the question is which of them a calibration-checked `auto` could pick (profiles/r05_operating_point_errors.txt)."""
+    g, kw, spec, sd, (patches, pos, scales) = load_ladder_case(name)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    ref32, ref64 = g["q"].astype(np.float64), g["q64"].astype(np.float64)
+    print(f"\n[{name}] reference scores: min {ref64.min():.3f} max {ref64.max():.3f} std {ref64.std():.3f}; reference fp32 vs its own fp64: "
+          f"{np.max(np.abs(ref32 - ref64) / np.abs(ref64)):.2e}")
+    loose = {"fp16x3": 1e-3, "bf16x3": 1e-3, "fp16x2": 5e-3, "fp16": 5e-2, "bf16": 3e-1}
+    for precision in ALL_MODES:
+        model = build(kw, sd, precision)
+        qs = []
+        with torch.no_grad():
+            for i in range(0, patches.shape[0], 32):
+                sl = slice(i, i + 32)
+                qs.append(model((p[0][sl], p[1][sl]), (ps[0][sl], ps[1][sl]), (None, None))[0])
+        q = torch.cat(qs).cpu().numpy().astype(np.float64)
+        assert np.isfinite(q).all()
+        raw32, raw64 = np.abs(q - ref32) / np.abs(ref32), np.abs(q - ref64) / np.abs(ref64)
+        print(f"[{name} {precision}] raw relative error of every score: vs reference fp32 max {raw32.max():.2e} p95 {np.percentile(raw32, 95):.2e}; "
+              f"vs reference fp64 max {raw64.max():.2e} p95 {np.percentile(raw64, 95):.2e}; max abs {np.abs(q - ref64).max():.2e}")
+        assert raw32.max() < loose[precision] and raw64.max() < loose[precision], (precision, raw32.max(), raw64.max())
+        del model
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("precision", ALL_MODES)
@@ -676,7 +706,7 @@ def test_gemm_tile_shapes_agree_end_to_end(name, precision):
     assert gate(got[-1], g["q"], TOL[precision]), rel_err(got[-1], g["q"])
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "fp16", "fp8"])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
 def test_repeated_forwards_are_bitwise_identical(precision):
     """Race detector for the persistent GEMM (DMA ring chained across tile boundaries, counted vmcnt, raw barriers) and every other
     kernel: the same batch 25 times -- interleaved with a different batch that reuses the workspace -- gives bit-identical scores."""

@@ -24,6 +24,31 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.vtq_abi_version.restype = ctypes.c_int
     assert lib.vtq_abi_version() == _lib.ABI_VERSION
+    # the fp8 experiment has a header of its own and is NOT in the product library ...
+    fp8_header = open(os.path.join(ROOT, "include", "vtamiq_hip_fp8.h")).read()
+    fp8_declared = set(re.findall(r"\b(vtq_[a-z0-9_]+)\s*\(", fp8_header))
+    assert fp8_declared == set(_lib.FP8_SIGNATURES), fp8_declared ^ set(_lib.FP8_SIGNATURES)
+    assert not (fp8_declared & declared)
+    if os.path.basename(_lib.LIB_PATH) == "libvtamiq_hip.so":
+        for name in fp8_declared:
+            assert not hasattr(lib, name), f"{name} is exported by the product library"
+    # ... and a build of the experiment (python -m vtamiq_amd.build --fp8) exports both sets
+    if os.environ.get("VTQ_TEST_FP8_BUILD", "1") == "1":
+        fp8_lib = ctypes.CDLL(build.build(verbose=False, fp8=True))
+        for name in declared | fp8_declared:
+            assert hasattr(fp8_lib, name), name
+
+
+def test_fp8_is_not_a_mode_of_the_product_model():
+    from vtamiq_amd import VTAMIQ, _lib
+    with pytest.raises(NotImplementedError, match="EXPERIMENT"):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False), precision="fp8")
+    assert not any(hasattr(VTAMIQ, n) for n in ("fp8_scales", "set_fp8_scales", "calibrate_fp8"))
+    if os.path.basename(_lib.LIB_PATH) == "libvtamiq_hip.so":
+        assert not _lib.has_fp8()
+        from vtamiq_amd.experimental_fp8 import VTAMIQFp8
+        with pytest.raises(RuntimeError, match="built without the fp8 experiment"):
+            VTAMIQFp8(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False))
 
 
 def test_config_struct_matches_header():
@@ -298,3 +323,20 @@ def test_weight_signature_sees_replacement_and_new_storage():
     assert m._signature() != s3
     m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})        # copy_ into the same parameters
     assert m._signature() != s3
+
+
+def test_weight_change_detection_is_scoped_to_the_model():
+    """importing the package registers no process-global torch hook, and modules built elsewhere in the process
+    neither invalidate a model's cached parameter walk nor pay for it."""
+    import torch.nn.modules.module as M
+    before = (len(M._global_parameter_registration_hooks), len(M._global_module_registration_hooks), len(M._global_buffer_registration_hooks))
+    from vtamiq_amd import VTAMIQ
+    assert (len(M._global_parameter_registration_hooks), len(M._global_module_registration_hooks), len(M._global_buffer_registration_hooks)) == before == (0, 0, 0)
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False), precision="bf16").eval()
+    s0 = m._signature()
+    cache = m.__dict__["_param_cache"]
+    other = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.LayerNorm(8))      # an unrelated module: registers parameters and submodules
+    other[0].weight = torch.nn.Parameter(torch.zeros(8, 8))
+    assert m._signature() == s0 and m.__dict__["_param_cache"] is cache            # same walk object: nothing was invalidated
+    m.q_predictor[4] = torch.nn.Linear(192, 1)                                      # a replacement inside THIS model is seen
+    assert m._signature() != s0 and m.__dict__["_param_cache"] is not cache

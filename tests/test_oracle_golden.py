@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
+from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, OPERATING_POINT_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
 import os
 
 # fp32 op-order differences between the restatement and the reference modules stay below this
@@ -76,6 +76,25 @@ def test_ladder_scores_at_baseline_patch_count(name):
     p64, ps64, _ = split_inputs(patches[:n], pos[:n], None, dtype=torch.float64)
     q64 = O.vtamiq_forward(sd64, spec, p64, ps64, (None, None))[0].numpy()
     assert np.max(np.abs(q64 - g["q64"][:n])) < 1e-10 * np.sqrt(np.mean(g["q64"] ** 2)) + 1e-12
+
+
+@pytest.mark.parametrize("name", OPERATING_POINT_CASES)
+def test_operating_point_ladder(name):
+    """The oracle against the reference on the ladder scored through a head at a trained model's operating point (scores in [0.2, 0.8],
+    tests.helpers.stress_state(head=True)): RAW relative error of EVERY score of a bounded sample (first 8 pairs), no rms floor; float64
+    is the same algorithm to 1e-12."""
+    g, kw, spec, sd, (patches, pos, scales) = load_ladder_case(name)
+    assert int(g["stress_head"]) == 1 and 0.2 < float(g["q64"].min()) and float(g["q64"].max()) < 0.8 and float(g["q64"].std()) > 0.05
+    n = 8
+    p, ps, sc = split_inputs(patches[:n], pos[:n], None)
+    q = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)[0].numpy()
+    e32, e64 = rel_err(q, g["q"][:n])["max_rel"], rel_err(q, g["q64"][:n])["max_rel"]
+    print(name, "oracle32-ref32", e32, "oracle32-ref64", e64)
+    assert e32 < 1e-4 and e64 < 1e-4, (e32, e64)
+    sd64 = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    p64, ps64, _ = split_inputs(patches[:n], pos[:n], None, dtype=torch.float64)
+    q64 = O.vtamiq_forward(sd64, spec, p64, ps64, (None, None))[0].numpy()
+    assert np.max(np.abs(q64 - g["q64"][:n])) < 1e-12
 
 
 def test_per_layer_tokens_c1():

@@ -4,6 +4,7 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vtamiq_amd import VTAMIQ, synth, _lib
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--patches", type=int, default=500)
@@ -12,7 +13,7 @@ ap.add_argument("--fused-ln", action="store_true", help="vtq_config.options & VT
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", nargs="+", default=["fp16x3", "fp16x2", "fp16", "fp8"])
 a = ap.parse_args()
 for prec in a.precision:
-    m = VTAMIQ(precision=prec, engine_options=_lib.OPT_FUSED_LAYERNORM if a.fused_ln else 0, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, pretrained=False),
+    m = model_class(prec)(precision=prec, engine_options=_lib.OPT_FUSED_LAYERNORM if a.fused_ln else 0, **(dict(vit_config=dict(variant="ViT-B16", num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, pretrained=False),
                                        ca_reduction=16) if a.refdefault else dict(vit_config=dict(variant="ViT-B16", pretrained=False))))
     sd = synth.make_state_dict(m.spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()

@@ -8,11 +8,12 @@ import torch.nn.functional as F
 from oracle import fp8_oracle as F8, vtamiq_oracle as O
 from tests.helpers import load_case, split_inputs
 from vtamiq_amd import VTAMIQ, _lib
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 
 ap = argparse.ArgumentParser(); ap.add_argument("--case", default="c1_b2_n50"); ap.add_argument("--layer", type=int, default=0)
 a = ap.parse_args()
 g, kw, spec, sd, (patches, pos, scales) = load_case(a.case)
-m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8", engine_options=_lib.OPT_FP8_STATIC_SCALES)   # the oracle's static scales (F8.S_*)
+m = model_class("fp8")(**json.loads(json.dumps(kw)), precision="fp8", engine_options=_lib.OPT_FP8_STATIC_SCALES)   # the oracle's static scales (F8.S_*)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
 p, ps, sc = split_inputs(patches, pos, scales, device="cuda")
 lib = _lib.load(); hip = C.CDLL("libamdhip64.so")

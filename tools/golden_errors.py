@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.helpers import E2E_CASES, STRESS_CASES, gate_error, load_case, rel_err, split_inputs
 from vtamiq_amd import VTAMIQ
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 MODES = ("fp16x3", "fp16x2", "bf16x3", "fp16", "bf16", "fp8")       # fp8: a different model (oracle/fp8_oracle.py), distance reported only
 print("# |q - q_ref| / |q_ref| against the goldens captured from the imported reference (fp32 CPU); min|q_ref|/rms shows how close to")
 print("# zero the smallest score of the case is.  columns per mode: raw max over all scores | raw max over |q_ref| >= 0.1 rms | max |d| / rms | gate")
@@ -21,7 +22,7 @@ for name in E2E_CASES + STRESS_CASES:      # the last two: the reference on trai
         if prec == "fp8" and spec.num_adapters > 0:
             print("    fp8     (adapters are not available in the fp8 mode)")
             continue
-        m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
+        m = model_class(prec)(**json.loads(json.dumps(kw)), precision=prec)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
         with torch.no_grad():
             q = m(p, ps, s3)[0].cpu().numpy().astype(np.float64)

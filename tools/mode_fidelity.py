@@ -15,6 +15,7 @@ import torch
 import bench
 from tests.helpers import stress_state
 from vtamiq_amd import VTAMIQ, synth
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=256)
@@ -34,7 +35,7 @@ for wname in a.weights:
     def make_model(prec):
         static = prec == "fp8-static"                       # the round-2 constants instead of the calibration on the first batch
         from vtamiq_amd import _lib
-        m = VTAMIQ(**json.loads(json.dumps(kw)), precision="fp8" if static else prec, engine_options=_lib.OPT_FP8_STATIC_SCALES if static else 0)
+        m = model_class("fp8" if static else prec)(**json.loads(json.dumps(kw)), precision="fp8" if static else prec, engine_options=_lib.OPT_FP8_STATIC_SCALES if static else 0)
         m.load_state_dict(state)
         return m.to(dev).eval()
     r = bench.mode_fidelity(torch, make_model, spec, sd_np, a.modes, dev, pairs=a.pairs, N=a.patches, threads=min(bench.effective_cores(), 64))

@@ -4,6 +4,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vtamiq_amd import VTAMIQ, synth
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 from oracle import vtamiq_oracle as O
 
 ap = argparse.ArgumentParser()
@@ -16,7 +17,7 @@ kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales, pretrained=Fal
 if a.refdefault:
     kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales, pretrained=False), ca_reduction=16)
 for prec in ("fp16x3", "fp16x2", "fp16", "bf16", "fp8"):
-    m = VTAMIQ(**json.loads(json.dumps(kw)), precision=prec)
+    m = model_class(prec)(**json.loads(json.dumps(kw)), precision=prec)
     spec = m.spec
     sd = synth.make_state_dict(spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()

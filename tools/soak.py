@@ -6,12 +6,13 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vtamiq_amd import VTAMIQ, synth
+from vtamiq_amd.experimental_fp8 import model_class      # VTAMIQFp8 for "fp8" (a build of the experiment), VTAMIQ otherwise
 
 ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=200); ap.add_argument("--modes", nargs="+", default=["fp16x3", "fp16x2", "fp16", "bf16x3", "fp8"])
 a = ap.parse_args()
 bad = 0
 for prec in a.modes:
-    m = VTAMIQ(vit_config=dict(variant="ViT-B16", pretrained=False), precision=prec)
+    m = model_class(prec)(vit_config=dict(variant="ViT-B16", pretrained=False), precision=prec)
     sd = synth.make_state_dict(m.spec, 0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); m = m.cuda().eval()
     patches, pos, _ = synth.make_inputs(m.spec, 32, 500, 7)

@@ -20,7 +20,7 @@ NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
 MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_FULL_LAST_LAYER = 1
 OPT_FP8_STATIC_SCALES = 2
 OPT_FUSED_LAYERNORM = 4
@@ -63,19 +63,12 @@ SIGNATURES = {
     "vtq_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vtq_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vtq_input_errors": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
-    "vtq_fp8_calibrate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "vtq_fp8_get_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
-    "vtq_fp8_set_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "vtq_k_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                              C.c_void_p]),
     "vtq_k_gemm_rowln": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "vtq_k_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "vtq_k_quant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
-    "vtq_k_gemm_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "vtq_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_skinny_linear": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -92,6 +85,19 @@ SIGNATURES = {
     "vtq_k_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "vtq_k_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+# the fp8 experiment (include/vtamiq_hip_fp8.h): exported only by a library built with -DVTQ_WITH_FP8 (python -m vtamiq_amd.build --fp8,
+# selected with VTQ_LIB_PATH); bound when present
+FP8_SIGNATURES = {
+    "vtq_fp8_calibrate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_fp8_get_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "vtq_fp8_set_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "vtq_k_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "vtq_k_quant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "vtq_k_gemm_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "vtq_fp8_reset": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
@@ -119,6 +125,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "vtq_fp8_calibrate"):
+        for name, (res, args) in FP8_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     if lib.vtq_abi_version() != ABI_VERSION:
         if not relaxed:
             raise RuntimeError(f"{LIB_PATH}: ABI version {lib.vtq_abi_version()}, this package binds version {ABI_VERSION} "
@@ -128,6 +139,11 @@ def load() -> C.CDLL:
                       "struct / argument layouts may differ -- measurement use only")
     _lib = lib
     return lib
+
+
+def has_fp8() -> bool:
+    """Is the loaded library a build of the fp8 experiment (-DVTQ_WITH_FP8)?  The product library is not."""
+    return hasattr(load(), "vtq_fp8_calibrate")
 
 
 def check(rc: int) -> None:

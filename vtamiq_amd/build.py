@@ -1,6 +1,8 @@
 """Builds libvtamiq_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m vtamiq_amd.build [--force]
+    python -m vtamiq_amd.build [--force]            the product library
+    python -m vtamiq_amd.build --fp8 [--force]      libvtamiq_hip_fp8.so: the same sources with -DVTQ_WITH_FP8, i.e. with the fp8 experiment
+                                                    (include/vtamiq_hip_fp8.h, vtamiq_amd/experimental_fp8.py); select it with VTQ_LIB_PATH
 """
 from __future__ import annotations
 
@@ -14,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libvtamiq_hip.so")
+LIB_FP8 = os.path.join(HERE, "libvtamiq_hip_fp8.so")
 SOURCES = ["gemm.hip", "gemm_st.hip", "gemm_rowln.hip", "attention.hip", "elementwise.hip", "head.hip", "skinny.hip", "cls_tail.hip", "patches.hip", "metrics.hip", "mfma_stream.hip", "engine.hip"]
-DEPS = ["dev_common.h", "kernels.h", os.path.join("..", "..", "include", "vtamiq_hip.h")]
+DEPS = ["dev_common.h", "kernels.h", os.path.join("..", "..", "include", "vtamiq_hip.h"), os.path.join("..", "..", "include", "vtamiq_hip_fp8.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (no v_accvgpr_read/write shuffles around the softmax)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
@@ -35,8 +38,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, fp8: bool = False) -> str:
     hipcc = _hipcc()
+    OBJ = os.path.join(CSRC, "_obj_fp8" if fp8 else "_obj")
+    LIB = LIB_FP8 if fp8 else globals()["LIB"]
+    extra = ["-DVTQ_WITH_FP8"] if fp8 else []
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
 
@@ -44,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get("VTQ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + os.environ.get("VTQ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -61,4 +67,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, fp8="--fp8" in sys.argv))

@@ -255,18 +255,26 @@ inline int grid_for(int64_t work, int block) {
 
 }  // namespace
 
-// dispatch on (f16, planes) -> K<T, NPL>
+// dispatch on (f16, planes) -> K<T, NPL>; e4m3 outputs (f16 == 2) exist in builds of the fp8 experiment only (-DVTQ_WITH_FP8)
+#ifdef VTQ_WITH_FP8
+#define VTQ_FMT_F8(f16_, npl_, CALL) else if ((f16_) == 2 && (npl_) == 1) { CALL(f8, 1); }
+#else
+#define VTQ_FMT_F8(f16_, npl_, CALL) else if ((f16_) == 2) return hipErrorNotSupported;
+#endif
 #define VTQ_FMT_DISPATCH(f16_, npl_, CALL)                      \
     do {                                                        \
         if (!(f16_) && (npl_) == 1) { CALL(bf16, 1); }          \
         else if (!(f16_) && (npl_) == 2) { CALL(bf16, 2); }     \
         else if ((f16_) == 1 && (npl_) == 1) { CALL(f16, 1); }  \
         else if ((f16_) == 1 && (npl_) == 2) { CALL(f16, 2); }  \
-        else if ((f16_) == 2 && (npl_) == 1) { CALL(f8, 1); }   \
+        VTQ_FMT_F8(f16_, npl_, CALL)                            \
         else return hipErrorInvalidValue;                       \
     } while (0)
 
 hipError_t launch_quant_rows_fp8(const float* src, void* dst, float* inv_scale, int N, int K, hipStream_t s, int Kp) {
+#ifndef VTQ_WITH_FP8
+    return hipErrorNotSupported;
+#endif
     if (Kp == 0) Kp = K;
     if (K % 4 || Kp % 4 || Kp < K) return hipErrorInvalidValue;
     hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, src, (uint8_t*)dst, inv_scale, N, K, Kp);

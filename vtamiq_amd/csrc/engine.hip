@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/vtamiq_hip.h"
+#include "../../include/vtamiq_hip_fp8.h"
 #include "kernels.h"
 
 using namespace vtq;
@@ -52,7 +53,7 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 // vtq_config.options & VTQ_OPT_FP8_STATIC_SCALES keeps the constants.  A value that still exceeds 448 after scaling is clamped and raises bit 2 of the
 // error word (vtq_input_errors).
 constexpr float kSPatch = 256.0f, kSLn = 8.0f, kSAtt = 16.0f, kSGelu = 4.0f;
-constexpr float kFp8Target = 224.0f;
+[[maybe_unused]] constexpr float kFp8Target = 224.0f;
 
 // Softmax scale of MultiHeadSelfAttention (transformer.py:158-160: scores / sqrt(head_dim), head_dim = 64) times log2(e): with the
 // 3-term attention the engine folds it into the query projection at weight ingestion, so that scores arrive in log2 units and the
@@ -721,6 +722,8 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
     if (c.num_adapters > 0 && c.precision == VTQ_PREC_FP8) return fail("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy)");
     if (c.patch_dim != 768 && c.patch_dim != 192) return fail("patch_dim %d unsupported (3*16*16 or 3*8*8)", c.patch_dim);
     if (c.num_layers < 1 || c.pos_grid < 1 || c.num_extra_tokens < 0) return fail("bad topology");
+    if (c.options & ~(VTQ_OPT_FULL_LAST_LAYER | VTQ_OPT_FP8_STATIC_SCALES | VTQ_OPT_FUSED_LAYERNORM)) return fail("unknown vtq_config.options bits 0x%x", c.options);
+    if ((c.options & VTQ_OPT_FUSED_LAYERNORM) && (c.mlp_dim % 32 || c.mlp_dim < 128)) return fail("VTQ_OPT_FUSED_LAYERNORM needs mlp_dim %% 32 == 0 and >= 128");
     if (c.calibrate && (c.num_rgs < 1 || c.num_rcabs < 1 || c.ca_hidden < 4 || c.ca_hidden % 4 || c.ca_hidden > 256))
         return fail("bad DiffNet topology (rgs %d, rcabs %d, ca_hidden %d)", c.num_rgs, c.num_rcabs, c.ca_hidden);
     vtq_engine* e = new vtq_engine();
@@ -731,7 +734,12 @@ int vtq_create(const vtq_config* cfg, vtq_handle* out) {
         case VTQ_PREC_FP16:   e->lin = Num{1, 1}; e->att = Num{1, 1}; break;
         case VTQ_PREC_FP16X3: e->lin = Num{1, 3}; e->att = Num{1, 3}; break;
         case VTQ_PREC_FP16X2: e->lin = Num{1, 2}; e->att = Num{1, 3}; break;     // attention keeps the 3-term form
+#ifdef VTQ_WITH_FP8
         case VTQ_PREC_FP8:    e->lin = Num{2, 1}; e->att = Num{1, 1}; e->fp8 = true; break;   // e4m3 linears, single-fp16 attention (2e-4 << the e4m3 step)
+#else
+        case VTQ_PREC_FP8:    delete e; return fail("precision 5 (fp8) is an experiment that this library was built without: build it with python -m vtamiq_amd.build --fp8 "
+                                                    "(include/vtamiq_hip_fp8.h, vtamiq_amd/experimental_fp8.py)");
+#endif
         default: delete e; return fail("unknown precision %d", c.precision);
     }
     e->f16 = e->fp8 ? 1 : e->lin.f16;          // fp8 mode: the QKV output is one fp16 plane (buffers are sized for it);
@@ -986,6 +994,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     return 0;
 }
 
+#ifdef VTQ_WITH_FP8
 int vtq_fp8_calibrate(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
                       const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
     if (!e || !e->fp8) return fail("vtq_fp8_calibrate: not an fp8 engine");
@@ -1024,6 +1033,14 @@ int vtq_fp8_set_scales(vtq_handle e, const float* in, int32_t n) {
     e->fp8_installed = true;
     return 0;
 }
+
+int vtq_fp8_reset(vtq_handle e) {
+    if (!e || !e->fp8) return fail("vtq_fp8_reset: not an fp8 engine");
+    e->fp8_calibrated = false;                 // the next forward calibrates on its own batch again
+    e->fp8_installed = false;
+    return 0;
+}
+#endif
 
 int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dist, const float* pos_ref, const float* pos_dist,
                 const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
@@ -1089,6 +1106,7 @@ int vtq_k_gemm_rowln(const void* A, int64_t a_plane, int32_t lda, const void* W,
     return 0;
 }
 
+#ifdef VTQ_WITH_FP8
 int vtq_k_quant_rows_fp8(const float* W, void* dst, float* inv_scale, int32_t N, int32_t K, void* stream) {
     if (!W || !dst || !inv_scale || N < 1 || K < 4) return fail("vtq_k_quant_rows_fp8: bad argument");
     HIP_TRY(launch_quant_rows_fp8(W, dst, inv_scale, N, K, (hipStream_t)stream));
@@ -1110,6 +1128,7 @@ int vtq_k_gemm_fp8(const void* A8, int32_t lda, const void* W8, const float* wsc
     HIP_TRY(launch_gemm(a, Num{2, 1}, epilogue, (hipStream_t)stream));
     return 0;
 }
+#endif
 
 int vtq_k_layernorm(const float* x, const float* w, const float* b, void* out, int64_t o_plane, int32_t rows, int32_t H,
                     int32_t f16, int32_t planes, void* stream) {

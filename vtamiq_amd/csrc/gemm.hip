@@ -1051,8 +1051,12 @@ hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) 
     const int bk2 = (num.f16 == 2) ? 256 : ((num.terms == 1) ? 128 : 64);     // two K tiles: the DMA ring's buffer parity is fixed across tiles
     if (a.M <= 0 || a.M % 256 || a.N % 256 || a.N > 4096 || a.K <= 0 || a.K % bk2 || a.lda % 16 || !num_valid(num)) return hipErrorInvalidValue;
     if (num.f16 == 2) {
+#ifdef VTQ_WITH_FP8                                   // the fp8 experiment (include/vtamiq_hip_fp8.h): not in the product library
         if (!a.wscale) return hipErrorInvalidValue;
         return launch_e<f8, 1>(a, epilogue, s);
+#else
+        return hipErrorNotSupported;
+#endif
     }
     if (!num.f16) {
         if (num.terms == 1) return launch_e<bf16, 1>(a, epilogue, s);

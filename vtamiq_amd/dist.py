@@ -48,14 +48,3 @@ def sharded_forward(model, patches, pos, scales, global_batch: int, group=None) 
     """Run the model on this rank's shard (inputs are the LOCAL shard) and return the gathered global scores."""
     q_local, _ = model(patches, pos, scales)
     return gather_scores(q_local, global_batch, group)
-
-
-def broadcast_fp8_scales(model, src: int = 0, group=None) -> None:
-    """fp8 mode: every rank calibrates its activation scales on its OWN shard's first batch, so the ranks of a data-parallel job
-    would score with different scales.  Call this once after the first forward (or after calibrate_fp8 on rank `src`): rank
-    `src`'s scales are installed on every rank (model.set_fp8_scales), which also keeps them across weight reloads."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return
-    box = [model.fp8_scales() if dist.get_rank(group) == src else None]
-    dist.broadcast_object_list(box, src=src, group=group)
-    model.set_fp8_scales(box[0])

@@ -32,20 +32,6 @@ _PRECISIONS = _lib.PRECISIONS
 DEFAULT_PRECISION = "auto"
 AUTO_FIRST, AUTO_FALLBACK = "fp16x3", "bf16x3"
 
-# Structure epoch: bumped whenever ANY module registers a parameter or a submodule (load_state_dict(assign=True), `m.sub = new`,
-# `m.weight = nn.Parameter(...)` all go through register_parameter / register_module).  A model whose cached parameter list was
-# taken in an older epoch walks its tree again; the cached walk is otherwise valid (replacement must not go unseen).
-_STRUCT_EPOCH = [0]
-
-
-def _bump_epoch(*_a, **_k):
-    _STRUCT_EPOCH[0] += 1
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
-torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
-
-
 class _Params(nn.Module):
     """A container whose forward must never run."""
 
@@ -161,6 +147,8 @@ def _residual_group(H, hid, num_rcabs):     # ResidualGroup.body (channel_attent
 
 
 class VTAMIQ(nn.Module):
+    _FP8_EXPERIMENT = False                       # vtamiq_amd.experimental_fp8.VTAMIQFp8 sets it
+
     def __init__(self, vit_config=None, calibrate=True, diff_scale=True, num_rgs=4, num_rcabs=4, rg_path_drop=0.1,
                  ca_reduction=8, predictor_dropout=0., return_features=False, precision: Optional[str] = None,
                  engine_options: int = 0, **kwargs):
@@ -194,11 +182,12 @@ class VTAMIQ(nn.Module):
             precision = "fp8"
         if precision != "auto" and precision not in _PRECISIONS:
             raise ValueError(f"precision must be 'auto' or one of {sorted(_PRECISIONS)}, got {precision!r}")
+        if precision == "fp8" and not self._FP8_EXPERIMENT:
+            raise NotImplementedError("precision 'fp8' is a throughput EXPERIMENT, not a scoring mode (SROCC 0.66 - 0.84 against the fp32 scores, "
+                                      "profiles/r04_fp8_study.txt), and is not part of this model class or of the shipped library: "
+                                      "vtamiq_amd.experimental_fp8.VTAMIQFp8 on a library built with `python -m vtamiq_amd.build --fp8`")
         self.precision = precision
         self._auto_fallback = False             # "auto" only: an fp16 operand overflowed, the engine now runs AUTO_FALLBACK
-        if precision == "fp8" and self.spec.num_adapters > 0:
-            raise NotImplementedError("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy of the "
-                                      "branch output); use a 16-bit precision")
         self._engine = None
         self._engine_device = None
         self._engine_precision = None
@@ -266,17 +255,43 @@ class VTAMIQ(nn.Module):
             set_grad(self.q_predictor, requires_grad)
 
     # ---- engine management --------------------------------------------------------------------------------
+    def _walk(self):
+        """The model's own tree as (module, name, parameter) and (parent, name, child) triples -- what _signature re-checks by identity
+        on every forward.  No process-global torch hook is involved: other modules in the process cost nothing and
+        change nothing here."""
+        params, mods = [], []
+        for mod in self.modules():
+            for name, p in mod._parameters.items():
+                if p is not None:
+                    params.append((mod, name, p))
+            for name, child in mod._modules.items():
+                if child is not None:
+                    mods.append((mod, name, child))
+        return params, mods
+
     def _signature(self):
-        """What the packed engine weights were made from: identity, storage and version of every parameter.  The module tree is
-        walked only when some module registered a parameter / submodule since the last walk (_STRUCT_EPOCH: parameter or module
-        REPLACEMENT, load_state_dict(assign=True)); the per-forward part is (data_ptr, _version) of the cached list, which sees
+        """What the packed engine weights were made from: identity, storage and version of every parameter.  The cached walk of the
+        module tree is re-validated by identity every forward (each parent still holds the same child module, each module the same
+        Parameter object: ~350 `is` checks) -- which sees parameter or module REPLACEMENT and load_state_dict(assign=True) anywhere in
+        THIS model's tree -- and re-done only when that fails; the rest is (data_ptr, _version) of the cached parameters, which sees
         `p.data = new_tensor` (new storage) and every in-place write that bumps the version counter (load_state_dict, optimizers).
         Not seen: in-place edits through `.data` (p.data.copy_()) -- refresh_weights()."""
         cache = self.__dict__.get("_param_cache")
-        if cache is None or cache[0] != _STRUCT_EPOCH[0]:
-            cache = (_STRUCT_EPOCH[0], list(self.parameters()))
+        if cache is not None:
+            params, mods = cache
+            for mod, name, p in params:
+                if mod._parameters.get(name) is not p:
+                    cache = None
+                    break
+            else:
+                for parent, name, child in mods:
+                    if parent._modules.get(name) is not child:
+                        cache = None
+                        break
+        if cache is None:
+            cache = self._walk()
             self.__dict__["_param_cache"] = cache
-        ps = cache[1]
+        ps = [p for _, _, p in cache[0]]
         return (tuple(map(id, ps)), tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps))
 
     def _release_engine(self):
@@ -308,11 +323,11 @@ class VTAMIQ(nn.Module):
         with torch.cuda.device(self._engine_device):
             stream = torch.cuda.current_stream(self._engine_device).cuda_stream
             _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
-        flags.value |= self.__dict__.pop("_flags_seen", 0)       # bits the fp8 mode's own early look already collected (and cleared)
+        flags.value |= self.__dict__.pop("_flags_seen", 0)       # bits an earlier look of a subclass already collected (and cleared)
         if flags.value & 1:
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
-        if flags.value & 4:
-            raise FloatingPointError("fp8 mode: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
+        if flags.value & 4:                         # raised by the fp8 experiment's kernels only
+            raise FloatingPointError("fp8 experiment: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
                                      "calibrated scales do not fit this data; calibrate_fp8() on a representative batch")
         if flags.value & 2:
             raise FloatingPointError(
@@ -362,19 +377,6 @@ class VTAMIQ(nn.Module):
                 warnings.warn("[VTAMIQ] non-finite scores in precision 'bf16x3': the inputs or weights of this call hold inf / NaN")
             if flags & 1:
                 raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
-        elif self.engine_precision == "fp8":
-            # the first forward calibrated the activation scales on its batch: remember them (a re-created engine gets them back), and
-            # look at the saturation bit on the first few forwards -- an asynchronous fp8 model must not clamp at +-448 unnoticed
-            if self.__dict__.get("_fp8_saved") is None:
-                self.fp8_scales()
-            n = self.__dict__.get("_fp8_checked", 0)
-            if n < 3 or self.validate_inputs:
-                self.__dict__["_fp8_checked"] = n + 1
-                flags = self._read_flags()
-                self.__dict__["_flags_seen"] = self.__dict__.get("_flags_seen", 0) | flags      # check_inputs() still reports them
-                if flags & 4:
-                    warnings.warn("[VTAMIQ] fp8 mode: an activation exceeded e4m3's range after scaling and was clamped to +-448 -- the "
-                                  "activation scales do not fit this data; calibrate_fp8() on a representative batch")
         elif self.validate_inputs:
             self.check_inputs()
 
@@ -395,7 +397,7 @@ class VTAMIQ(nn.Module):
             _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
             self._engine, self._engine_device, self._engine_precision = h, device, self.engine_precision
             self._weights_sig = None
-            self.__dict__["_fp8_reinstall"] = self.__dict__.get("_fp8_saved") is not None
+            self._engine_created()
         sig = self._signature()
         if sig != self._weights_sig:
             sd = self.state_dict()
@@ -412,16 +414,17 @@ class VTAMIQ(nn.Module):
                 keep.append(t)
                 descs[i] = _lib.VtqTensorDesc(k.encode(), t.data_ptr(), t.numel())
             stream = torch.cuda.current_stream(device).cuda_stream
-            if self._weights_sig is not None and not self.__dict__.get("_fp8_user"):
-                self.__dict__["_fp8_saved"] = None      # other weights: scales calibrated on the old ones are dropped (the engine recalibrates)
+            reload_ = self._weights_sig is not None
             _lib.check(lib.vtq_load_weights(self._engine, descs, len(names), stream))
             self._weights_sig = sig
-        if self.__dict__.get("_fp8_reinstall") and self.engine_precision == "fp8":
-            # a re-created engine (.to(), device change) keeps the scales this model already ran with instead of calibrating on
-            # whatever batch comes next: fp8 scores stay reproducible across engine lifetimes
-            self.__dict__["_fp8_reinstall"] = False
-            self._install_fp8(self.__dict__["_fp8_saved"])
+            self._weights_loaded(reload_)
         return lib
+
+    def _engine_created(self):                    # hooks of the fp8 experiment's subclass (state that must follow the engine's lifetime)
+        pass
+
+    def _weights_loaded(self, reload_: bool):
+        pass
 
     def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameter storage (possibly the objects) is replaced
         self._weights_sig = None
@@ -518,62 +521,6 @@ class VTAMIQ(nn.Module):
             self._launch_checked(device, lambda lib: _lib.check(lib.vtq_forward_pairwise(
                 self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N, q.data_ptr(), stream)))
         return q[:B], q[B:]
-
-    # ---- fp8 mode: activation scales ----------------------------------------------------------------------------
-    def fp8_scales(self):
-        """The engine's per-tensor activation scales of the fp8 mode: {"patch": s, "ln1": [L], "att": [L], "ln2": [L], "gelu": [L]}
-        (powers of two).  They are calibrated on the batch of the first forward (include/vtamiq_hip.h vtq_fp8_*);
-        calibrate_fp8() repeats that on a batch of your choice, set_fp8_scales() installs given ones."""
-        if self._engine is None or self.engine_precision != "fp8":
-            raise RuntimeError("fp8_scales: no fp8 engine yet (run a forward first)")
-        lib = _lib.load()
-        n = lib.vtq_fp8_get_scales(self._engine, None, 0)
-        buf = (C.c_float * n)()
-        lib.vtq_fp8_get_scales(self._engine, buf, n)
-        v = list(buf)
-        L = (n - 1) // 4
-        sc = {"patch": v[0], "ln1": v[1::4][:L], "att": v[2::4][:L], "ln2": v[3::4][:L], "gelu": v[4::4][:L]}
-        if not self.__dict__.get("_fp8_user"):
-            self.__dict__["_fp8_saved"] = sc            # what a re-created engine gets back (see _ensure_engine)
-        return sc
-
-    def _install_fp8(self, sc):
-        L = len(sc["ln1"])
-        flat = [sc["patch"]]
-        for i in range(L):
-            flat += [sc["ln1"][i], sc["att"][i], sc["ln2"][i], sc["gelu"][i]]
-        buf = (C.c_float * len(flat))(*flat)
-        _lib.check(_lib.load().vtq_fp8_set_scales(self._engine, buf, len(flat)))
-
-    def set_fp8_scales(self, sc):
-        """Install activation scales (the dict fp8_scales() returns, e.g. from a checkpoint's side file or from rank 0:
-        dist.broadcast_fp8_scales).  Installed scales survive weight reloads and engine re-creation; calibrate_fp8() replaces them."""
-        if self.precision != "fp8":
-            raise RuntimeError("set_fp8_scales: precision is not 'fp8'")
-        self.__dict__["_fp8_saved"] = {k: (list(v) if isinstance(v, (list, tuple)) else float(v)) for k, v in sc.items()}
-        self.__dict__["_fp8_user"] = True
-        if self._engine is not None:
-            self._install_fp8(self.__dict__["_fp8_saved"])
-
-    def calibrate_fp8(self, patches, pos, scales):
-        """Re-calibrate the fp8 activation scales on this batch (arguments as forward()); returns the batch's scores."""
-        if self.precision != "fp8":
-            raise RuntimeError("calibrate_fp8: precision is not 'fp8'")
-        device = patches[0].device
-        use_scales = self.spec.use_scale_embedding
-        with torch.cuda.device(device):
-            lib = self._ensure_engine(device)
-            t = [self._prep(x, device) for x in (patches[0], patches[1], pos[0], pos[1])]
-            sc = [self._prep(x, device) for x in scales] if use_scales else [None, None]
-            B, N = patches[0].shape[:2]
-            q = torch.empty(B, device=device, dtype=torch.float32)
-            stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.vtq_fp8_calibrate(self._engine, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
-                                             sc[0].data_ptr() if use_scales else None, sc[1].data_ptr() if use_scales else None,
-                                             B, N, q.data_ptr(), stream))
-        self.__dict__["_fp8_user"] = False
-        self.fp8_scales()                               # remembered for engine re-creation
-        return q
 
     # ---- measurement helpers (bench.py) ---------------------------------------------------------------------
     def profile_enable(self, classes):
