@@ -566,6 +566,12 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         bstep = 1;
     }
     if (b0 >= b1) return;
+#if defined(VTQ_SW_SEAM_STAGGER) && VTQ_SW_SEAM_STAGGER > 0
+    // Measurement builds (tools/runs/r05g_attn_seams.sh): every second workgroup of an XCD starts VTQ_SW_SEAM_STAGGER microseconds late, so that the
+    // block seams of the chip (Q loads, output stores) do not coincide; s_sleep 32 = ~2048 cycles = ~1 us.  Same results.
+    if ((blockIdx.x >> 3) & 1)
+        for (int i = 0; i < VTQ_SW_SEAM_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
     const int NT = ((b1 - b0 + bstep - 1) / bstep) * nt;
     const float sc = 0.125f * 1.4426950408889634f;
 #ifdef VTQ_ATTN_DIAG

@@ -25,6 +25,23 @@ inline bool num_valid(Num n) {
     return (n.terms == 1 || n.terms == 3 || (n.terms == 2 && n.f16 == 1)) && (n.f16 == 0 || n.f16 == 1);
 }
 
+// ---- Every build switch of csrc/, in one place.  The PRODUCT library (python -m vtamiq_amd.build) defines NONE of them: the
+// code under them is measurement or experiment code that no shipped kernel contains (tests/test_layout.py greps the shipped objects).  Builds with
+// switches are made by tools/build_abl.sh NAME "-D..." into tools/_abl/NAME.so and loaded through VTQ_LIB_PATH.
+//   VTQ_WITH_FP8          the fp8 experiment (include/vtamiq_hip_fp8.h; python -m vtamiq_amd.build --fp8): e4m3 GEMM instantiations, fp8 entry points
+//   VTQ_MEASURE           makes VTQ_MEASURE_ENV getenv: VTQ_GEMM_FLAGS / _CUS / _CG / _SCHED / _STAGGER, VTQ_ATTN_VARIANT, VTQ_ATTN_LDS_PAD (A/B runs)
+//   VTQ_GEMM_DIAG         gemm.hip: s_memtime / s_memrealtime stamps around K loops, kernel and epilogue steps; shadow-VALU filler (profiles/r03_clock.txt)
+//   VTQ_EPI_ABL=1..4      gemm.hip epilogue ablations: 1 no GELU arithmetic, 2 no copy-out, 3 no global stores, 4 no LDS staging (r03_gemm_epilogue_ablation.txt)
+//   VTQ_EPI_ORDER=1|2     gemm.hip: both wave groups copy first / convert first in an epilogue interval
+//   VTQ_RESID_PLANES      gemm.hip: pricing build of a LayerNorm fold's producer side (profiles/r03_ln_fold_price.txt)
+//   VTQ_GEMM_ST_EXPLORE   gemm_st.hip: extra tile shapes and the load-only / compute-only modes of tools/st_bench.py (profiles/r05_gemm_tile_shapes.txt)
+//   VTQ_RL_ABL, VTQ_RL_MM, VTQ_RL_PRE, VTQ_RL_POST   gemm_rowln.hip: K-loop ablations, MFMA statement form, waits (profiles/r04_rowln_anatomy.txt)
+//   VTQ_ATTN_DIAG         attention.hip: per-wave phase stamps (profiles/r03_attention_anatomy.txt)
+//   VTQ_ATTN_NO_VMASK     attention.hip: without the zeroing of masked keys' V rows (profiles/r04_attention_vmask_ab.txt)
+//   VTQ_SW_NOFILL / NOMFMA / NOSTORE / NOQ / NODMA / PAIRED / DIST / HALFREADS   attention.hip pipelined kernel: skeleton ablations, read-ahead distance
+//   VTQ_SW_SEAM_STAGGER=n attention.hip: every second workgroup of an XCD starts n us late (profiles/r05_attention_seams.txt)
+//   VTQ_LIBM_ERF          dev_common.h: erff() instead of the fitted exact-erf GELU (accuracy cross-check)
+//
 // Measurement knobs.  The PRODUCT library reads no environment variable and executes no measurement branch: every knob below exists only
 // in builds with -DVTQ_MEASURE (tools/build_abl.sh), where VTQ_MEASURE_ENV is getenv; in the shipped build it is a null constant (the
 // variable names do not even appear in the objects: tests/test_layout.py greps for them) and GemmArgs::flags is ignored by the kernels.
