@@ -6,7 +6,7 @@ plus size-independent properties at BASELINE.json's full size (B=32, N=500).
 Tolerance (BASELINE.json north_star): scores within 1e-3 RELATIVE of the fp32 CPU reference.  The gate is the RAW per-score
 relative error |q - q_ref| / |q_ref| wherever |q_ref| >= 0.1 rms(q_ref); random-init scores cross zero (one golden score is 6e-4
 against an rms of 2e-2), and for those near-zero scores the denominator is rms(q_ref) (helpers.gate_error).
-profiles/r02_golden_errors.txt holds the raw table of every case and mode (tools/golden_errors.py).
+profiles/archive/r02_golden_errors.txt holds the raw table of every case and mode (tools/golden_errors.py).
 Only precision="fp16x3" (the model's default) claims the north-star tolerance: its worst golden case is 4e-5.  The other modes
 are measured against looser bounds that are stated here, not hidden -- smoke bounds against gross errors, NOT parity claims:
   "bf16x3" 3e-3 (golden cases <= 3.2e-4; the round-1 parity mode, kept: it misses 1e-3 raw on small scores of ViT-L cases),

@@ -9,7 +9,7 @@
 //   * Both operands are K-contiguous (torch Linear layout) and go global -> LDS by 16-byte LDS-DMA
 //     (global_load_lds_dwordx4).  The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128
 //     fragment reads are removed by XOR-swizzling the 16-byte chunk index on the SOURCE address and on the read
-//     (SQ_LDS_BANK_CONFLICT: 2 % of the launch's cycles for the 16-bit forms, profiles/r02_gemm_fc1_pmc.txt).
+//     (SQ_LDS_BANK_CONFLICT: 2 % of the launch's cycles for the 16-bit forms, profiles/archive/r02_gemm_fc1_pmc.txt).
 //   * A K tile is four half-tile REGIONS (A rows 0-127 | 128-255, W rows 0-127 | 128-255).  Every wave owns 64 rows
 //     of EACH A half and 32 columns of EACH W half, so an MFMA cluster on quadrant (mh, nh) touches exactly one A
 //     region and one W region and regions are released early -> a DMA ring over two K-tile buffers that runs up to
