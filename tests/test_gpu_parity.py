@@ -631,6 +631,15 @@ def test_default_model_nan_inputs_do_not_change_its_mode():
     assert torch.equal(q[0], q_good[0])                         # and the healthy pair of the batch scores the same bits as before
     with torch.no_grad():
         assert torch.equal(auto(p, ps, sc)[0], q_good)          # and the next healthy batch scores as before, in the parity mode
+    # the probe's bf16x3 engine is parked with its packed weights, not destroyed: a second bad batch builds and re-packs nothing
+    parked = auto.__dict__["_parked"]
+    assert "bf16x3" in parked and parked["bf16x3"][1] is not None
+    h_bf16, h_fp16 = parked["bf16x3"][0].value, auto._engine.value
+    with warnings.catch_warnings(record=True), torch.no_grad():
+        warnings.simplefilter("always")
+        q2 = auto(bad_p, ps, sc)[0]
+    assert torch.equal(torch.isnan(q2), torch.isnan(q)) and torch.equal(q2[0], q_good[0])
+    assert auto.__dict__["_parked"]["bf16x3"][0].value == h_bf16 and auto._engine.value == h_fp16 and auto.engine_precision == "fp16x3"
 
 
 def test_library_ignores_measurement_environment(monkeypatch):

@@ -39,6 +39,21 @@ def test_library_exports_every_declared_symbol():
             assert hasattr(fp8_lib, name), name
 
 
+def test_vtq_create_rejects_unknown_option_bits_before_touching_the_device():
+    """unknown vtq_config.options bits and a fused-LayerNorm mlp_dim the kernel cannot run are errors at vtq_create (host-side
+    validation: no GPU needed), not a bare hipErrorInvalidValue at the first forward."""
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    base = dict(hidden_size=768, mlp_dim=3072, num_heads=12, num_layers=1, patch_dim=768, pos_grid=24, num_extra_tokens=0, num_scales=0,
+                use_layer_scale=0, calibrate=1, diff_scale=1, num_rgs=1, num_rcabs=1, ca_hidden=96, precision=_lib.PREC_FP16X3, num_adapters=0)
+    h = ctypes.c_void_p()
+    cfg = _lib.VtqConfig(**base, options=64)
+    assert lib.vtq_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"options" in lib.vtq_last_error()
+    cfg = _lib.VtqConfig(**dict(base, precision=_lib.PREC_FP8), options=0)
+    if not _lib.has_fp8():
+        assert lib.vtq_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"experiment" in lib.vtq_last_error()
+
+
 def test_fp8_is_not_a_mode_of_the_product_model():
     from vtamiq_amd import VTAMIQ, _lib
     with pytest.raises(NotImplementedError, match="EXPERIMENT"):

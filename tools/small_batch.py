@@ -34,7 +34,9 @@ for B in a.batches:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        th = time.perf_counter()
         for _ in range(a.steps): m(*args)
+        host_ms = (time.perf_counter() - th) / a.steps * 1e3       # host time to ENQUEUE a forward (the queue is deep enough not to block at these step counts)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.steps
         # one forward at a time (latency of a single query: the host waits for every score)
@@ -43,9 +45,9 @@ for B in a.batches:
             m(*args); torch.cuda.synchronize()
         ms_sync = (time.perf_counter() - t0) / a.steps * 1e3
         f = m.spec.flops_per_pair_executed(a.patches, cls_prune=True)
-        row = {"B": B, "rows": 2 * B * m.spec.seq_len(a.patches), "ms_per_forward": ms, "ms_per_forward_synchronous": ms_sync, "ms_per_pair": ms / B,
+        row = {"B": B, "rows": 2 * B * m.spec.seq_len(a.patches), "ms_per_forward": ms, "ms_per_forward_synchronous": ms_sync, "host_enqueue_ms_per_forward": host_ms, "ms_per_pair": ms / B,
                "pairs_per_s": B / ms * 1e3, "forward_mfma_frac": B / ms * 1e3 * f / PEAK}
-        print(f"{B:3d} {row['rows']:6d} {ms:11.3f} {ms / B:9.3f} {row['pairs_per_s']:9.1f} {row['forward_mfma_frac']:9.4f}   (synchronous: {ms_sync:.3f} ms)")
+        print(f"{B:3d} {row['rows']:6d} {ms:11.3f} {ms / B:9.3f} {row['pairs_per_s']:9.1f} {row['forward_mfma_frac']:9.4f}   (synchronous: {ms_sync:.3f} ms; host enqueue {host_ms:.3f} ms)")
         if a.classes:
             m.profile_enable(list(_lib.KERNEL_CLASSES))
             for _ in range(a.steps): m(*args)

@@ -14,7 +14,9 @@
 // tests of test_gpu_parity.py run across the selection boundary).
 //
 // Structure (cdna_hip_programming.md section 5: "128^2 tile / grouped GEMM at 2-3 blocks/CU", glds + counted vmcnt + raw barrier):
-//   * one workgroup per BM x BN tile, WR x WC waves, each wave a (BM/WR) x (BN/WC) sub-tile of 16x16 accumulator blocks;
+//   * one workgroup per BM x BN tile: WR x WC MFMA waves, each a (BM/WR) x (BN/WC) sub-tile of 16x16 accumulator blocks, plus NPW PRODUCER waves that
+//     do nothing but issue the LDS-DMA of the ring, wait for it (counted vmcnt) and synchronise: with one MFMA wave per SIMD nothing else would run
+//     beside a wave's DMA issue and landing wait (the load path alone and the compute path alone each take ~2/3 of what they took together);
 //   * operands global -> LDS by 16-byte LDS-DMA into a ring of NST stages; a stage is one 64-deep K slice (two 32-deep k-steps side
 //     by side) with the LDS image [plane][row][128 B], so that every DMA wave-instruction reads 8 full 128-byte lines
 //     ("x through LDS in full 128-B lines"); the image is lane-linear per DMA piece (NT/8 rows), the 16-byte chunk index
@@ -24,14 +26,19 @@
 //     the barrier that precedes its first read, and re-staged after the barrier that follows its last read (retired by lgkmcnt(0));
 //   * epilogue straight from the accumulators (a lane holds 4 consecutive columns of one row: 8-byte plane stores, 16-byte fp32
 //     read-modify-write of the residual stream);
-//   * tile -> workgroup map: workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns a contiguous run of the row-major
-//     tile order, so the column tiles of a row panel share their A panel through one L2.
-// What bounds it (profiles/r05_gemm_tile_shapes.txt): the L1 -> LDS fill rate of a CU (~90 GB/s with the loads alone, 60 - 70 GB/s beside
-// the fragment reads) -- a 64x64 tile moves 32 KiB per 24 MFMAs per wave; so small tiles only pay while the 256x256 form leaves most
-// CUs idle (gemm.hip gemm_tile_rule).
+//   * tile -> workgroup map: workgroup b runs on XCD b % 8 (round-robin dispatch); the 8 XCDs form a gr x gc grid over the tile grid, chosen on the host
+//     so that what an XCD pulls through its L2 -- 1/gr of A (freshly written: Infinity Cache) + 1/gc of W (a layer's weights are COLD inside a
+//     forward: HBM) -- is smallest.
+// What bounds it (profiles/r05_gemm_tile_shapes.txt): with WARM operands (a benchmark that re-uses one weight buffer) a CU's L1 -> LDS fill rate (~90 GB/s
+// with the loads alone) -- a 64x64 tile moves 32 KiB per 24 MFMAs per wave -- and how well the load and compute paths overlap: DMA-only producer waves
+// beside the MFMA waves take 24 - 27 % off the B = 1 out-proj / fc2 there.  Inside a forward every layer's weights are COLD (HBM: 344 MB of weights against a
+// 256 MB Infinity Cache) and the W stream of a column tile is one dependent chain of 128-byte-per-row stage fetches that all the XCD's row panels wait on:
+// the B = 1 fc2 takes ~31 us cold whatever the ring depth, the XCD grid or a W-prefetching wave (built, slower), against 23 us warm; the producers' gain
+// inside a forward is 3 - 10 %.  So small tiles only pay while the 256x256 form leaves most CUs idle (gemm.hip gemm_tile_rule).
 #include "dev_common.h"
 #include "kernels.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace vtq {
@@ -45,11 +52,14 @@ template <int N> __device__ __forceinline__ void st_wait_vm() {
 
 // MODE (exploration builds only): 0 = the kernel; 1 = no fragment reads / MFMAs (the load path alone); 2 = no LDS-DMA (compute + barriers
 // alone); 3 = 2 without the barriers; 4 = 2 without the fragment reads; 5 = MFMAs alone
-template <typename T, int TERMS, int EPI, int BM, int BN, int WR, int WC, int NST, int MODE = 0>
-__global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
+// NPW: producer waves.  0: the WR x WC MFMA waves issue the LDS-DMA themselves.  > 0: NPW extra waves do nothing but issue the DMA, wait for it and
+// synchronise -- the MFMA waves then spend no issue slots on DMA addressing and never stall on vmcnt (one wave per SIMD has nothing else to overlap with).
+template <typename T, int TERMS, int EPI, int BM, int BN, int WR, int WC, int NST, int MODE = 0, int NPW = 0>
+__global__ __launch_bounds__(64 * (WR * WC + NPW)) void gemm_st_kernel(GemmArgs p) {
     typedef typename Vec<T>::x8 tx8;
     typedef typename Vec<T>::x4 tx4;
-    constexpr int NT = 64 * WR * WC;
+    constexpr int NCW = WR * WC;                          // MFMA waves
+    constexpr int NT = 64 * (NPW ? NPW : NCW);            // threads that issue the DMA
     constexpr int APL = (TERMS == 1) ? 1 : 2, WPL = (TERMS == 3) ? 2 : 1;
     constexpr int WM = BM / WR, WN = BN / WC, MI = WM / 16, NJ = WN / 16;
     constexpr int KS = 2, ROWB = 128;                     // k-steps per stage; bytes of an LDS row
@@ -61,14 +71,17 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
     static_assert(NST >= 2 && NST <= 5 && (NST - 2) * G <= 63, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // ---- tile of this workgroup (XCD-contiguous runs of the row-major order; bijective for any tile count) ------------------
-    const int ntn = p.N / BN, nt = (p.M / BM) * ntn;
+    // ---- tile of this workgroup.  Workgroup b runs on XCD b % 8 (round-robin dispatch).  The 8 XCDs form a gr x gc grid over the tile grid (host-chosen,
+    // launch_gemm_st): XCD (xr, xc) owns the row panels [xr ntm / gr, (xr + 1) ntm / gr) x the column tiles [xc ntn / gc, ...), walked column-major, so that
+    // consecutive workgroups share a W tile.  What an XCD pulls into its L2 is then 1/gr of A and 1/gc of W.
+    const int ntn = p.N / BN, ntm = p.M / BM;
+    const int gr = p.st_grid >> 4, gc = p.st_grid & 15;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int q = nt >> 3, r = nt & 7;
-    const int cnt = q + (xcd < r ? 1 : 0);
-    if (j >= cnt) return;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const int tm = t / ntn, tn = t - tm * ntn;
+    const int xr = xcd / gc, xc = xcd - xr * gc;
+    const int r0 = xr * ntm / gr, nr = (xr + 1) * ntm / gr - r0;
+    const int c0 = xc * ntn / gc, nc = (xc + 1) * ntn / gc - c0;
+    if (j >= nr * nc) return;
+    const int tn = c0 + j / nr, tm = r0 + (j - (j / nr) * nr);
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
 
@@ -77,10 +90,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
     const int wr = wave / WC, wc = wave - wr * WC;
     const int lane = tid & 63, fr = lane & 15, fq = lane >> 4;
     const int nkt = p.K / 64;
+    const bool producer = NPW > 0 && wave >= NCW;         // wave-uniform
+    const int dtid = NPW ? tid - NCW * 64 : tid, dwave = NPW ? wave - NCW : wave;      // position among the DMA-issuing threads / waves
 
     // ---- DMA addressing ---------------------------------------------------------------------------------------------------------
-    const int prow = tid >> 3;
-    const int pch = (tid & 7) ^ ((prow >> 1) & 7);
+    const int prow = dtid >> 3;
+    const int pch = (dtid & 7) ^ ((prow >> 1) & 7);
     const uint32_t a_off = (uint32_t)(prow * p.lda + pch * 8) * 2u;
     const uint32_t w_off = (uint32_t)(prow * p.K + pch * 8) * 2u;
     const char* Ag = (const char*)p.A + m0 * p.lda * 2;
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
     const int64_t a_rb = (int64_t)PR * p.lda * 2, w_rb = (int64_t)PR * p.K * 2;
     auto issue = [&](int kt, int s) {
         if constexpr (MODE >= 2) return;
-        char* dst = smem + s * STAGE + wave * 1024;
+        char* dst = smem + s * STAGE + dwave * 1024;
         const int kb = kt * ROWB;                         // byte column of the stage
 #pragma unroll
         for (int pl = 0; pl < APL; ++pl)
@@ -100,6 +115,27 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
 #pragma unroll
             for (int rb = 0; rb < PW; ++rb) glds16(Wg + pl * w_pl + rb * w_rb + kb + w_off, dst + SUB_A + (pl * BN + rb * PR) * ROWB);
     };
+    // ---- producer waves: the DMA ring and nothing else (they leave BEFORE the tile's ordinary loads: their wave index is no MFMA-wave position) -------
+    if constexpr (NPW > 0) {
+        if (producer) {
+#pragma unroll
+            for (int s = 0; s < NST - 1; ++s)
+                if (s < nkt) issue(s, s);
+            int slot = 0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int rem = nkt - kt - 1, st = rem < NST - 2 ? rem : NST - 2;
+                if (st <= 0) st_wait_vm<0>();
+                else if (st == 1) st_wait_vm<(G <= 63) ? G : 63>();
+                else if (st == 2) st_wait_vm<(2 * G <= 63) ? 2 * G : 63>();
+                else st_wait_vm<(3 * G <= 63) ? 3 * G : 63>();
+                __builtin_amdgcn_s_barrier();             // stage kt is published; the MFMA waves have retired their reads of stage kt - 1
+                if (kt + NST - 1 < nkt) issue(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
+                slot = (slot == NST - 1) ? 0 : slot + 1;
+            }
+            return;
+        }
+    }
+
     // fragment read offsets: k-step ks of a stage = chunks 4 ks .. 4 ks + 3 of the 128-byte rows
     int rdA[KS], rdW[KS];
 #pragma unroll
@@ -137,9 +173,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
             e_i2[i] = p.table2 ? p.idx2[m] : 0;
         }
     }
+    if constexpr (NPW == 0) {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nkt) issue(s, s);
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nkt) issue(s, s);
+    }
     f32x4 acc[MI][NJ];
 #pragma unroll
     for (int jn = 0; jn < NJ; ++jn)
@@ -179,6 +217,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
     };
     // counted wait: all but the `stages` youngest stages of this thread's LDS-DMA have landed (stages is clamped to what the ring holds)
     auto wait_stages = [&](int stages) {
+        if constexpr (NPW > 0) return;                    // the MFMA waves issue no DMA
         if (stages <= 0) st_wait_vm<0>();
         else if (stages == 1) st_wait_vm<(G <= 63) ? G : 63>();
         else if (stages == 2) st_wait_vm<(2 * G <= 63) ? 2 * G : 63>();
@@ -193,7 +232,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (MODE != 3 && MODE != 5) __builtin_amdgcn_s_barrier();
         // re-stage the slot read in iteration kt - 1
-        if (kt + NST - 1 < nkt) issue(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
+        if constexpr (NPW == 0)
+            if (kt + NST - 1 < nkt) issue(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
         const char* buf = smem + slot * STAGE;
         if constexpr (MODE >= 4) {         // exploration: no fragment reads (the same registers every k-step)
             Frag f;
@@ -282,12 +322,29 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_st_kernel(GemmArgs p) {
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------
-template <typename T, int TERMS, int EPI, int BM, int BN, int WR, int WC, int NST, int MODE = 0>
+// The XCD grid (rows x columns, product 8) that minimises what one XCD reads: M / gr rows of A + kColdW x N / gc rows of W (same K, same planes);
+// W counts double: inside a forward it comes from HBM, A from the Infinity Cache.  Only grids that leave no XCD without tiles.
+constexpr int kColdW = 2;
+int st_xcd_grid(int M, int N, int ntm, int ntn) {
+    static const int forced = [] { const char* v = VTQ_MEASURE_ENV("VTQ_ST_GRID"); return v ? atoi(v) : 0; }();   // measurement builds: rows * 16 + columns
+    if (forced) return forced;
+    int best = (8 << 4) | 1;
+    long best_cost = -1;
+    for (int gr = 8; gr >= 1; gr >>= 1) {
+        const int gc = 8 / gr;
+        if (gr > ntm || gc > ntn) continue;
+        const long cost = (long)M / gr + (long)kColdW * N / gc;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = (gr << 4) | gc; }
+    }
+    return best;
+}
+
+template <typename T, int TERMS, int EPI, int BM, int BN, int WR, int WC, int NST, int MODE = 0, int NPW = 0>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
     constexpr int APL = (TERMS == 1) ? 1 : 2, WPL = (TERMS == 3) ? 2 : 1;
     constexpr int LDS = NST * (APL * BM + WPL * BN) * 128;
     static_assert(LDS <= 163840, "LDS ring");
-    auto kern = gemm_st_kernel<T, TERMS, EPI, BM, BN, WR, WC, NST, MODE>;
+    auto kern = gemm_st_kernel<T, TERMS, EPI, BM, BN, WR, WC, NST, MODE, NPW>;
     if constexpr (LDS > 65536) {
         static std::mutex mu;
         static bool configured[64] = {false};
@@ -302,23 +359,37 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
             configured[dev] = true;
         }
     }
-    const int nt = (a.M / BM) * (a.N / BN);
-    const int grid = 8 * ((nt + 7) / 8);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WR * WC), LDS, s, a);
+    const int ntm = a.M / BM, ntn = a.N / BN;
+    GemmArgs b = a;
+    b.st_grid = st_xcd_grid(a.M, a.N, ntm, ntn);
+    const int gr = b.st_grid >> 4, gc = b.st_grid & 15;
+    const int grid = 8 * ((ntm + gr - 1) / gr) * ((ntn + gc - 1) / gc);       // workgroups beyond an XCD's rectangle leave at once
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (WR * WC + NPW)), LDS, s, b);
     return hipGetLastError();
 }
 
 template <typename T, int TERMS, int EPI> hipError_t launch_shape(const GemmArgs& a, int variant, hipStream_t s) {
     switch (variant) {
-        case GEMM_ST_64: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3>(a, s);          // ring of 3: 96 KiB (3-term formats), one workgroup per CU
-        case GEMM_ST_64X2: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 2>(a, s);        // ring of 2: 64 KiB, two workgroups per CU
-        case GEMM_ST_128: return launch_v<T, TERMS, EPI, 128, 128, 2, 4, 2>(a, s);       // 8 waves, ring of 2: 128 KiB
+        // MFMA waves 2x2 (64x64) or 2x4 (128x128) + DMA-only producer waves (profiles/r05_gemm_tile_shapes.txt: -24 .. -27 % on the B = 1 out-proj / fc2,
+        // -16 .. -18 % on the 128x128 fc2 of B = 3 .. 5 against the same tiles with the MFMA waves issuing the DMA themselves)
+        case GEMM_ST_64: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 0, 2>(a, s);    // ring of 3: 96 KiB (3-term formats), one workgroup per CU; 4 + 2 waves
+        case GEMM_ST_64X2: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 2, 0, 4>(a, s);  // ring of 2: 64 KiB, two workgroups per CU; 4 + 4 waves
+        case GEMM_ST_128: return launch_v<T, TERMS, EPI, 128, 128, 2, 4, 2, 0, 8>(a, s); // ring of 2: 128 KiB; 8 + 8 waves
 #ifdef VTQ_GEMM_ST_EXPLORE                                   // tile-shape exploration builds (tools/st_bench.py): not in the product library
+        case 9: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3>(a, s);                   // the three shapes WITHOUT producer waves
+        case 10: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 2>(a, s);
+        case 18: return launch_v<T, TERMS, EPI, 128, 128, 2, 4, 2>(a, s);
         case 4: return launch_v<T, TERMS, EPI, 128, 64, 2, 2, 3>(a, s);
         case 5: return launch_v<T, TERMS, EPI, 64, 128, 2, 2, 3>(a, s);
         case 6: return launch_v<T, TERMS, EPI, 128, 128, 2, 2, 2>(a, s);
         case 7: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 4>(a, s);
         case 8: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 5>(a, s);
+        case 20: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 0, 4>(a, s);
+        case 21: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 2, 0, 4>(a, s);
+        case 22: return launch_v<T, TERMS, EPI, 128, 128, 2, 4, 2, 0, 4>(a, s);
+        case 23: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 0, 2>(a, s);
+        case 24: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 4, 0, 4>(a, s);
+        case 25: return launch_v<T, TERMS, EPI, 128, 128, 2, 4, 2, 0, 8>(a, s);
         case 11: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 1>(a, s);
         case 12: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 2>(a, s);
         case 13: return launch_v<T, TERMS, EPI, 64, 64, 2, 2, 3, 3>(a, s);

@@ -90,6 +90,7 @@ struct GemmArgs {
     const float* wscale; float ascale_inv; float out_scale;
     Fp8Obs obs;                                   // fp8 GELU form only (the one GEMM epilogue that writes e4m3 bytes)
     const int* sched;                             // set by launch_gemm: per-workgroup tile lists (gemm.hip build_schedule)
+    int st_grid;                                  // set by launch_gemm_st: the XCD grid of the small-tile kernels, rows * 16 + columns (gemm_st.hip)
     int flags;                                    // set by launch_gemm: GEMM_FLAG_* (-DVTQ_MEASURE builds; the product kernels read 0, gemm_flags())
     // diagnostic builds (-DVTQ_GEMM_DIAG, tools/build_abl.sh) only; set by launch_gemm from gemm_set_diag, never read otherwise:
     unsigned long long* diag;                     //   per workgroup 8 words: K-loop and whole-kernel s_memtime / s_memrealtime sums

@@ -294,12 +294,29 @@ class VTAMIQ(nn.Module):
         ps = [p for _, _, p in cache[0]]
         return (tuple(map(id, ps)), tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps))
 
-    def _release_engine(self):
+    def _release_engine(self, park: bool = False):
+        """Destroy the engine -- or, park=True (the numerics mode changes on the same device: "auto" probing bf16x3 and coming back), keep
+        it with its packed weights under its precision, so that a batch with non-finite inputs does not cost two engine builds and two
+        weight re-packs per call.  Without park, parked engines are destroyed too."""
         eng = self.__dict__.get("_engine")
+        parked = self.__dict__.setdefault("_parked", {})
         if eng is not None:
-            _lib.load().vtq_destroy(eng)
+            if park:
+                parked[self.__dict__.get("_engine_precision")] = (eng, self.__dict__.get("_weights_sig"))
+            else:
+                _lib.load().vtq_destroy(eng)
+        if not park:
+            for h, _ in parked.values():
+                _lib.load().vtq_destroy(h)
+            parked.clear()
         self.__dict__["_engine"] = None
         self.__dict__["_weights_sig"] = None
+
+    def _forget_packed_weights(self):
+        self.__dict__["_weights_sig"] = None
+        parked = self.__dict__.get("_parked") or {}
+        for k, (h, _) in list(parked.items()):
+            parked[k] = (h, None)
 
     def __del__(self):
         try:
@@ -312,7 +329,7 @@ class VTAMIQ(nn.Module):
         `.data` (p.data.copy_(), p.data.normal_(), ...): those do not bump the version counter `_signature` watches, so the
         engine would keep serving the previously packed weights.  load_state_dict / .to() / optimizer-style in-place ops on
         the parameters themselves are picked up automatically; weights.load_* call this for you."""
-        self._weights_sig = None
+        self._forget_packed_weights()
 
     def check_inputs(self):
         """Synchronise and raise IndexError if any forward since the last check saw a position outside [0, 1), FloatingPointError
@@ -382,8 +399,15 @@ class VTAMIQ(nn.Module):
 
     def _ensure_engine(self, device: torch.device):
         lib = _lib.load()
-        if self._engine is not None and (self._engine_device != device or self._engine_precision != self.engine_precision):
+        if self._engine is not None and self._engine_device != device:
             self._release_engine()
+        elif self._engine is not None and self._engine_precision != self.engine_precision:
+            self._release_engine(park=True)
+        parked = self.__dict__.get("_parked") or {}
+        if self._engine is None and self.engine_precision in parked:
+            h, sig = parked.pop(self.engine_precision)
+            self._engine, self._engine_device, self._engine_precision = h, device, self.engine_precision
+            self._weights_sig = sig
         if self._engine is None:
             s = self.spec
             cfg = _lib.VtqConfig(
@@ -427,7 +451,7 @@ class VTAMIQ(nn.Module):
         pass
 
     def _apply(self, fn, *a, **k):            # .to()/.cuda()/.float(): parameter storage (possibly the objects) is replaced
-        self._weights_sig = None
+        self._forget_packed_weights()
         self.__dict__["_param_cache"] = None
         return super()._apply(fn, *a, **k)
 
