@@ -1,4 +1,8 @@
 #!/bin/bash
-O=gpurun_out/r05q; mkdir -p $O
-for g in 0 24 36; do echo "## VTQ_ST_GRID=$g" >> $O/st_pf2.txt; VTQ_ST_GRID=$g VTQ_LIB_PATH=$PWD/tools/_abl/stx.so timeout 300 python3 tools/st_bench.py --variants 1 26 29 3 28 30 --batches 1 2 4 --cold 40 2>&1 | grep -v amdgpu >> $O/st_pf2.txt; done
-cut -c1-400 $O/st_pf2.txt
+# W-prefetch wave (one tile per XCD and W column tile touches the tile's W lines once): cold and warm, against the shipped shapes
+O=gpurun_out/r05q; mkdir -p $O; : > $O/st_pf2.txt
+echo "## cold weights (40 buffers)" >> $O/st_pf2.txt
+VTQ_LIB_PATH=$PWD/tools/_abl/stx2.so timeout 400 python3 tools/st_bench.py --variants 0 1 26 2 27 3 28 --batches 1 2 4 --cold 40 2>&1 | grep -v amdgpu >> $O/st_pf2.txt
+echo "## warm (one weight buffer)" >> $O/st_pf2.txt
+VTQ_LIB_PATH=$PWD/tools/_abl/stx2.so timeout 400 python3 tools/st_bench.py --variants 0 1 26 2 27 3 28 --batches 1 2 4 2>&1 | grep -v amdgpu >> $O/st_pf2.txt
+cut -c1-420 $O/st_pf2.txt
