@@ -12,7 +12,8 @@ the device (validate.compute_correlations_cat_flat reduces them there).
         scores.append(q)
     # or, without the host copy: img, smp, sid = pipe.acquire(); <decode into the pinned views>; q = pipe.launch()
 
-Measured (bench.py `e2e`): 0.986 x the forward's own throughput at B = 32, N = 500.
+Measured (bench.py `e2e`, profiles/r05_bench_line.json): the loop sustains 0.98 x the forward's own throughput at B = 32, N = 500; with a 1 280-pair
+validation set's final reductions (rank statistics + the logistic fit, once per set) 0.91 - 0.95 x by box.
 """
 from __future__ import annotations
 
