@@ -190,6 +190,19 @@ def test_attention_kernel_rule():
     assert rule(64, 257, 768, "fp16x3") == 2                                                # one row past 256
 
 
+def test_gemm_tile_rule_is_host_only():
+    """Which tile shape launch_gemm picks (gemm.hip gemm_tile_rule; pure host code): the persistent 256x256 kernel from 64 of its tiles up, below
+    that 64x64 tiles while they fit one (<= 256) or two (<= 512) co-resident workgroups per CU, 128x128 beyond; never small tiles for fp8."""
+    from vtamiq_amd import _lib
+    lib = _lib.load()
+    rule = lambda M, N, K, fmt="fp16x3": lib.vtq_k_gemm_tile_rule(M, N, K, _lib.NUM[fmt])
+    rows = lambda B, S=501: (2 * B * S + 255) // 256 * 256
+    assert [rule(rows(B), 768, 3072) for B in (1, 2, 3, 4, 5, 6, 8, 32)] == [1, 2, 3, 3, 3, 0, 0, 0]          # fc2 / out-proj
+    assert [rule(rows(B), 2304, 768) for B in (1, 2, 32)] == [3, 0, 0] and [rule(rows(B), 3072, 768) for B in (1, 2)] == [3, 0]
+    assert rule(256, 768, 768, "bf16") == 1 and rule(256, 256, 256, "fp16x2") == 1 and rule(1024, 768, 768, "fp8") == 0
+    assert lib.vtq_k_gemm_tile_rule(1024, 768, 768, 99) == -1
+
+
 def test_gemm_tile_schedule_covers_every_tile_once():
     """The host-built persistent schedule of the GEMM (gemm.hip build_schedule): 256 per-workgroup lists; every 256x256 tile
     appears exactly once, either whole or as its top AND bottom half; half tiles close a list, or -- one of them, on the odd XCDs
