@@ -55,14 +55,18 @@ def embeddings(sd: Dict[str, Tensor], spec, patches: Tensor, pos: Tensor, scales
     B, N = patches.shape[:2]
     e = "transformer.embeddings."
     x = patch_embed(sd, patches)
-    table = sd[e + "positional_embeddings.positional_embeddings"][0]          # (G*G+1, H)
-    x = x + table[pos_index(pos.reshape(B * N, 2), spec.pos_grid)].view(B, N, -1)
+    use_pos = getattr(spec, "use_pos_embedding", True)
+    if use_pos:                                                               # transformer.py:539-543
+        table = sd[e + "positional_embeddings.positional_embeddings"][0]      # (G*G+1, H)
+        x = x + table[pos_index(pos.reshape(B * N, 2), spec.pos_grid)].view(B, N, -1)
     if spec.use_scale_embedding:
         if scales is None:
             raise ValueError("Model uses scale embedding but scales is passed as None.")   # transformer.py:547-548
         st = sd[e + "scale_embeddings.scale_embeddings"][0]
         x = x + st[scale_index(scales.reshape(B * N), spec.num_scales)].view(B, N, -1)
-    cls = sd[e + "cls_token"].expand(B, 1, -1) + table[0]                     # CLS gets pos row 0 (:511-516)
+    cls = sd[e + "cls_token"].expand(B, 1, -1)
+    if use_pos:
+        cls = cls + table[0]                                                  # CLS gets pos row 0 (:511-516)
     toks = [cls]
     if spec.num_extra_tokens > 0:
         toks.append(sd[e + "extra_tokens"].expand(B, spec.num_extra_tokens, -1))   # no pos/scale (:520-523)

@@ -414,6 +414,10 @@ def main():
         run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
         run_patches(P=8, fname="patches_gather_p8.npz", seed=12)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--nopos":          # only the use_pos_embedding=False case (added in round 5)
+        run_case("nopos_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_pos_embedding=False, num_extra_tokens=1, num_scales=2)),
+                 B=2, N=40, wseed=23, iseed=20)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--fullsize":       # only the two full-size score goldens (added in round 4; ~3 min)
         run_fullsize()
         return
@@ -446,6 +450,8 @@ def main():
     run_case("vitb8_b2_n90", dict(vit_config=dict(variant="ViT-B8", num_keep_layers=3, num_scales=2)), B=2, N=90, wseed=8, iseed=18)
     run_case("adapters_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, num_adapters=2, use_layer_scale=True, num_extra_tokens=1)),
              B=2, N=40, wseed=22, iseed=19)
+    run_case("nopos_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_pos_embedding=False, num_extra_tokens=1, num_scales=2)),
+             B=2, N=40, wseed=23, iseed=20)
     run_stress()
     run_ladder()
     run_operating_point()

@@ -56,6 +56,20 @@ def test_golden(name, precision):
     assert gate(q.cpu().numpy(), g["q"], TOL[precision]), e
 
 
+def test_pos_is_not_looked_at_without_positional_embedding():
+    """use_pos_embedding=False: the reference never touches `pos` (transformer.py:539), so None, or coordinates that would index past
+    the table, give the same scores as the golden's -- bit for bit, and without the IndexError of a model that has a table."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("nopos_b2_n40")
+    model = build(kw, sd, "auto")
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    with torch.no_grad():
+        q0, _ = model(p, ps, sc)
+        q1, _ = model(p, (None, None), sc)
+        q2, _ = model(p, (ps[0] + 7.0, ps[1] - 3.0), sc)
+    assert gate(q0.cpu().numpy(), g["q"], TOL["fp16x3"])
+    assert torch.equal(q0, q1) and torch.equal(q0, q2)
+
+
 @pytest.mark.parametrize("precision", ALL_MODES + ["auto"])
 @pytest.mark.parametrize("name", FULLSIZE_CASES)
 def test_golden_at_the_bench_sizes(name, precision):

@@ -130,6 +130,19 @@ def test_rejected_configs():
     assert m.spec.num_adapters == 2 and sum("adapter" in k for k in m.state_dict()) == 16
     with pytest.raises(ValueError):
         VTAMIQ(vit_config=dict(variant="ViT-H14"))
+    with pytest.raises(NotImplementedError):
+        VTAMIQ(vit_config=dict(variant="ViT-B16", use_patch_embedding=False, pretrained=False))   # pre-embedded input: outside the path
+
+
+def test_model_without_positional_embedding_has_no_table():
+    """use_pos_embedding=False (backbone.py:21, transformer.py:497-499): no UvPosEmbedding module, so no key for it in the state_dict
+    -- a checkpoint of such a reference model loads strictly -- and set_freeze_state steps over it like the reference's try/except."""
+    from vtamiq_amd import VTAMIQ
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, use_pos_embedding=False, pretrained=False))
+    assert not m.spec.use_pos_embedding and not any("positional" in k for k in m.state_dict())
+    assert sorted(m.state_dict()) == sorted(k for k, _, _ in m.spec.state_layout())
+    m.set_freeze_state(True, dict(freeze_dict_vit=None, freeze_quality_decoder=True, freeze_q_predictor=True))
+    assert not any(p.requires_grad for p in m.transformer.parameters())
 
 
 def test_flop_model_matches_baseline_md():

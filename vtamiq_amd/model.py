@@ -65,11 +65,12 @@ class _Embeddings(_Params):                 # Embeddings (transformer.py:458-505
         self.cls_token = nn.Parameter(torch.zeros(1, 1, H).normal_(std=0.02))
         if spec.num_extra_tokens > 0:
             self.extra_tokens = nn.Parameter(torch.zeros(1, spec.num_extra_tokens, H).normal_(std=0.02))
-        self.positional_embeddings = _UvPos(spec.pos_grid ** 2 + 1, H)
+        if spec.use_pos_embedding:
+            self.positional_embeddings = _UvPos(spec.pos_grid ** 2 + 1, H)
         if spec.use_scale_embedding:
             self.scale_embeddings = _ScaleEmb(spec.num_scales + 1, H)
         self.num_tokens = spec.num_tokens
-        self.use_pos_embedding = True
+        self.use_pos_embedding = spec.use_pos_embedding
         self.use_scale_embedding = spec.use_scale_embedding
 
 
@@ -245,7 +246,7 @@ class VTAMIQ(nn.Module):
             tr.embeddings.extra_tokens.requires_grad = requires_grad
         if freeze_all or fd["freeze_embeddings_patch"]:
             set_grad(tr.embeddings.patch_embeddings, requires_grad)
-        if freeze_all or fd["freeze_embeddings_pos"]:
+        if (freeze_all or fd["freeze_embeddings_pos"]) and tr.embeddings.use_pos_embedding:
             set_grad(tr.embeddings.positional_embeddings, requires_grad)
         if (freeze_all or fd["freeze_embeddings_scale"]) and tr.embeddings.use_scale_embedding:
             set_grad(tr.embeddings.scale_embeddings, requires_grad)
@@ -429,6 +430,12 @@ class VTAMIQ(nn.Module):
             missing = [k for k in names if k not in sd]
             if missing:
                 raise RuntimeError(f"state_dict is missing {missing[:3]}...")
+            if not self.spec.use_pos_embedding:
+                # use_pos_embedding=False (transformer.py:497-499, 514, 539): the model has no table and the reference adds nothing to the
+                # patch rows or to CLS.  The engine's embedding epilogue always adds a table row: it gets a table of zeros (x + 0 = x).
+                pk = "transformer.embeddings.positional_embeddings.positional_embeddings"
+                names.append(pk)
+                sd[pk] = torch.zeros(1, self.spec.pos_grid ** 2 + 1, self.spec.hidden_size, device=device, dtype=torch.float32)
             keep = []
             descs = (_lib.VtqTensorDesc * len(names))()
             for i, k in enumerate(names):
@@ -484,6 +491,10 @@ class VTAMIQ(nn.Module):
         B, N, Cc, P, P2 = patches_ref.shape
         if (Cc, P, P2) != (3, self.spec.patch_size, self.spec.patch_size):
             raise ValueError(f"patch shape {(Cc, P, P2)} != (3,{self.spec.patch_size},{self.spec.patch_size})")
+        if not self.spec.use_pos_embedding:
+            # the reference never looks at `pos` then (transformer.py:539): whatever was passed, None included, has no effect.  The
+            # engine's index kernel still wants coordinates: zeros (table row 1 of the all-zero table _ensure_engine installs)
+            pos_ref = pos_dist = torch.zeros(B, N, 2, device=device, dtype=torch.float32)
         if tuple(pos_ref.shape) != (B, N, 2) or tuple(pos_dist.shape) != (B, N, 2):
             raise ValueError("pos must be two (B,N,2) tensors")
         use_scales = self.spec.use_scale_embedding
@@ -519,7 +530,7 @@ class VTAMIQ(nn.Module):
         reference image encoded once: 3B sequences instead of 4B."""
         if self.training:
             raise NotImplementedError("the MI355X engine implements the eval/no-grad forward only: call model.eval()")
-        if len(patches) != 3 or len(pos) != 3:
+        if len(patches) != 3 or (self.spec.use_pos_embedding and len(pos) != 3):
             raise ValueError("forward_pairwise expects (ref, dist1, dist2) triplets")
         device = patches[0].device
         if device.type != "cuda":
@@ -529,6 +540,8 @@ class VTAMIQ(nn.Module):
         for t in patches:
             if tuple(t.shape) != (B, N, 3, self.spec.patch_size, self.spec.patch_size):
                 raise ValueError(f"patches must be three (B,N,3,P,P) tensors, got {tuple(t.shape)}")
+        if not self.spec.use_pos_embedding:            # as in forward(): `pos` is not looked at
+            pos = (torch.zeros(B, N, 2, device=device, dtype=torch.float32),) * 3
         for t in pos:
             if tuple(t.shape) != (B, N, 2):
                 raise ValueError("pos must be three (B,N,2) tensors")

@@ -95,6 +95,8 @@ def load_vit_npz(model, npz) -> None:
     weights = np.load(npz) if isinstance(npz, (str, bytes)) or hasattr(npz, "__fspath__") else npz
     spec = model.spec
     sd = convert_vit_npz(weights, spec.hidden_size, spec.num_layers, spec.pos_grid ** 2 + 1)
+    if not spec.use_pos_embedding:                      # transformer.py:656-657: the table is read only into a model that has one
+        sd.pop("transformer.embeddings.positional_embeddings.positional_embeddings")
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if unexpected:
         raise RuntimeError(f"unexpected keys from the ViT checkpoint: {unexpected[:4]}")
