@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 6
+#define VTQ_ABI_VERSION 7
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -124,6 +124,11 @@ int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float
  * (Bit 2 is raised by the fp8 experiment only: include/vtamiq_hip_fp8.h.)
  * This call synchronises `stream`, returns the flags accumulated since the last call and clears them. */
 int  vtq_input_errors(vtq_handle h, int32_t* flags, void* stream);
+
+/* Which token row of the encoder output the head consumes: VTAMIQ.token_num (vtamiq.py:57, 107-108: "can be CLS token or
+ * extra_token").  0 = CLS (the reference's and this library's default), 1 .. num_extra_tokens = a register token.  Applies to every
+ * later vtq_forward / vtq_forward_pairwise; an index outside the model's tokens is refused (the reference would read a PATCH row). */
+int  vtq_set_iqa_token(vtq_handle h, int32_t token);
 
 /* Debug tap: when buf != NULL, every later vtq_forward also writes the pre-final-LN token rows after the
  * embedding and after each layer: buf[(L+1)][2B][T][H] fp32 (ref sequences first).  Mirrors

@@ -175,9 +175,9 @@ def q_predictor(sd, x: Tensor) -> Tensor:
     return (h @ sd["q_predictor.4.weight"].t() + sd["q_predictor.4.bias"]).flatten()
 
 
-def head(sd, spec, tok_ref: Tensor, tok_dist: Tensor) -> Tensor:
-    """vtamiq.py:104-117 from the (B,T,H) token rows: token 0 diff -> diff_scale -> quality_decoder -> q_predictor."""
-    d = tok_ref[:, 0] - tok_dist[:, 0]
+def head(sd, spec, tok_ref: Tensor, tok_dist: Tensor, token_num: int = 0) -> Tensor:
+    """vtamiq.py:104-117 from the (B,T,H) token rows: token `token_num` (vtamiq.py:57: 0) diff -> diff_scale -> quality_decoder -> q_predictor."""
+    d = tok_ref[:, token_num] - tok_dist[:, token_num]
     if spec.diff_scale:
         d = d * sd["diff_scale.gamma"]
     return q_predictor(sd, quality_decoder(sd, spec, d))
@@ -185,7 +185,7 @@ def head(sd, spec, tok_ref: Tensor, tok_dist: Tensor) -> Tensor:
 
 @torch.no_grad()
 def vtamiq_forward(sd: Dict[str, Tensor], spec, patches: Sequence[Tensor], pos: Sequence[Tensor],
-                   scales: Sequence[Optional[Tensor]], trace: Optional[dict] = None) -> Tuple[Tensor, None]:
+                   scales: Sequence[Optional[Tensor]], trace: Optional[dict] = None, token_num: int = 0) -> Tuple[Tensor, None]:
     """VTAMIQ.forward (eval mode).  vtamiq.py:94-119.  Returns (q, None) like the reference."""
     tr_r = [] if trace is not None else None
     tr_d = [] if trace is not None else None
@@ -193,7 +193,7 @@ def vtamiq_forward(sd: Dict[str, Tensor], spec, patches: Sequence[Tensor], pos: 
     t_dist = vit_tokens(sd, spec, patches[1], pos[1], scales[1], tr_d)
     if trace is not None:
         trace["tokens_ref"], trace["tokens_dist"] = torch.stack(tr_r), torch.stack(tr_d)
-    return head(sd, spec, t_ref, t_dist), None
+    return head(sd, spec, t_ref, t_dist, token_num), None
 
 
 def predict(sd, spec, batch, use_scales: Optional[bool] = None, dtype=torch.float32):

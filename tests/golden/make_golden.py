@@ -102,7 +102,7 @@ def load_seeded(model, spec, seed, stress_qk=None):
     return sd
 
 
-def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False, stress_qk=None):
+def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False, stress_qk=None, token_num=None):
     kw = json.loads(json.dumps(vtamiq_kwargs))
     spec = make_spec(**json.loads(json.dumps(kw)))
     if trace:
@@ -130,6 +130,11 @@ def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False,
         q, aux = model(p, ps, sc)
         assert aux is None
         out["q"] = q.numpy().astype(np.float32)
+        if token_num is not None:           # the same model with a register token as the IQA token (vtamiq.py:57, 107-108)
+            model.token_num = int(token_num)
+            out["token_num"] = np.int64(token_num)
+            out["q_token"] = model(p, ps, sc)[0].numpy().astype(np.float32)
+            model.token_num = 0
         if trace:
             for side, (pp, pq, s_) in (("ref", (p[0], ps[0], sc[0])), ("dist", (p[1], ps[1], sc[1]))):
                 x, _, hidden = model.forward_vit(pp, pq, s_, tokens_only=True)
@@ -418,6 +423,10 @@ def main():
         run_case("nopos_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_pos_embedding=False, num_extra_tokens=1, num_scales=2)),
                  B=2, N=40, wseed=23, iseed=20)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--token":          # only the token_num case (added in round 5): CLS scores + register-token scores
+        run_case("token2_b3_n45", dict(vit_config=dict(variant=B16, num_keep_layers=3, num_extra_tokens=3, use_layer_scale=True)),
+                 B=3, N=45, wseed=32, iseed=21, token_num=2)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--fullsize":       # only the two full-size score goldens (added in round 4; ~3 min)
         run_fullsize()
         return
@@ -452,6 +461,8 @@ def main():
              B=2, N=40, wseed=22, iseed=19)
     run_case("nopos_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_pos_embedding=False, num_extra_tokens=1, num_scales=2)),
              B=2, N=40, wseed=23, iseed=20)
+    run_case("token2_b3_n45", dict(vit_config=dict(variant=B16, num_keep_layers=3, num_extra_tokens=3, use_layer_scale=True)),
+             B=3, N=45, wseed=32, iseed=21, token_num=2)
     run_stress()
     run_ladder()
     run_operating_point()

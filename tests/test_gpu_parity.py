@@ -56,6 +56,31 @@ def test_golden(name, precision):
     assert gate(q.cpu().numpy(), g["q"], TOL[precision]), e
 
 
+@pytest.mark.parametrize("options", [0, _lib.OPT_FULL_LAST_LAYER])
+@pytest.mark.parametrize("precision", ["auto", "bf16x3", "fp16"])
+def test_token_num_selects_the_iqa_token(precision, options):
+    """model.token_num (vtamiq.py:57, 107-108: "can be CLS token or extra_token") is read at every forward, like the reference reads
+    it: register token 2 gives the reference's scores for that token (pruned and full last layer), back to 0 the CLS scores, and an
+    index that is not a token of the model is refused (the reference would silently read a patch row)."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("token2_b3_n45")
+    model = build(kw, sd, precision, engine_options=options)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    tol = TOL["fp16x3" if precision == "auto" else precision]
+    with torch.no_grad():
+        q0 = model(p, ps, sc)[0].cpu().numpy()
+        model.token_num = int(g["token_num"])
+        q2 = model(p, ps, sc)[0].cpu().numpy()
+        q2p = torch.cat(model.forward_pairwise((p[0], p[1], p[1]), (ps[0], ps[1], ps[1]), None if sc[0] is None else (sc[0], sc[1], sc[1]))).cpu().numpy()
+        model.token_num = 0
+        q0b = model(p, ps, sc)[0].cpu().numpy()
+        model.token_num = spec.num_tokens
+        with pytest.raises(RuntimeError, match="vtq_set_iqa_token"):
+            model(p, ps, sc)
+    assert gate(q0, g["q"], tol), rel_err(q0, g["q"])
+    assert gate(q2, g["q_token"], tol), rel_err(q2, g["q_token"])
+    assert np.array_equal(q0, q0b) and np.array_equal(np.concatenate([q2, q2]), q2p)
+
+
 def test_pos_is_not_looked_at_without_positional_embedding():
     """use_pos_embedding=False: the reference never touches `pos` (transformer.py:539), so None, or coordinates that would index past
     the table, give the same scores as the golden's -- bit for bit, and without the IndexError of a model that has a table."""

@@ -22,6 +22,16 @@ def test_e2e_q(name):
     assert e["max_abs"] < 1e-6, e
 
 
+def test_e2e_q_from_a_register_token():
+    """VTAMIQ.token_num (vtamiq.py:57, 107-108): the reference with a register token as the IQA token."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case("token2_b3_n45")
+    p, ps, sc = split_inputs(patches, pos, scales)
+    q, _ = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc, token_num=int(g["token_num"]))
+    e = rel_err(q.numpy(), g["q_token"])
+    assert e["max_rel_rms"] < ORACLE_RTOL and e["max_abs"] < 1e-6, e
+    assert np.abs(g["q_token"] - g["q"]).max() > 1e-3        # a different token gives different scores
+
+
 @pytest.mark.parametrize("name", FULLSIZE_CASES)
 def test_e2e_q_at_the_bench_sizes(name):
     """The reference's scores at the sizes bench.py runs (B = 32, N = 500, L = 12; reference-default topology B = 16, N = 512) and at BASELINE

@@ -141,6 +141,7 @@ struct vtq_engine {
     int* err_flag = nullptr;             // device word (vtq_input_errors): bit 0 = a position outside [0, 1) was clamped, bit 1 = non-finite CLS difference
     std::vector<void*> ws_allocs;
     float* trace = nullptr;
+    int iqa_token = 0;                          // vtamiq.py:57, 107-108: the token row the head consumes (0 = CLS, 1 .. = register tokens)
     // profiling
     uint32_t prof_mask = 0;
     struct Ev { hipEvent_t a, b; int cls; };
@@ -496,7 +497,7 @@ int run_encoder(vtq_engine* e, const Geometry& g, hipStream_t s, bool prune) {
                     return a;
                 };
                 const PlaneOut tl{e->tl, e->tl_plane, H, f16, apl, nullptr};       // every row kernel of the tail writes its consumer's planes
-                HIP_TRY(launch_rows_ln(x, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, tl, s));
+                HIP_TRY(launch_rows_ln(x + (int64_t)e->iqa_token * H, (int64_t)g.S_pad * H, Ly.ln1w, Ly.ln1b, lncls, xcls, R, H, tl, s));
                 {   // query projection: rows 0 .. H-1 of the packed QKV weight
                     SkinnyArgs a = stage(e->tl, e->tl_plane, H, Ly.wqkv, Ly.pqkv, H, H, Ly.bqkv);
                     a.epi = SK_PLAIN; a.y = qcls; a.ldy = H; a.ycols = H;
@@ -836,6 +837,14 @@ int vtq_set_token_trace(vtq_handle e, float* buf) {
     return 0;
 }
 
+int vtq_set_iqa_token(vtq_handle e, int32_t token) {
+    if (!e) return fail("null handle");
+    if (token < 0 || token > e->cfg.num_extra_tokens)
+        return fail("vtq_set_iqa_token: token %d outside [0, %d] (CLS + num_extra_tokens register tokens)", (int)token, (int)e->cfg.num_extra_tokens);
+    e->iqa_token = token;
+    return 0;
+}
+
 int vtq_debug_stop_after(vtq_handle e, int32_t stage) {
     if (!e) return fail("null handle");
     e->dbg_stop = stage;
@@ -987,7 +996,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         float* d = e->hb[0];
         const PlaneOut hp{e->hp[0], e->hp_plane, H, 1, 2, head_first_slope(e)};      // the first head stage's input planes
         if (prune) HIP_TRY(launch_final_diff(e->xcls, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, SeqMap{1, g.nseq, 0}, H, hp, s, e->err_flag));
-        else HIP_TRY(launch_final_diff(e->x, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s, e->err_flag));
+        else HIP_TRY(launch_final_diff(e->x + (int64_t)e->iqa_token * H, e->encw, e->encb, c.diff_scale ? e->diff_gamma : nullptr, d, B, ndist, g.sm, H, hp, s, e->err_flag));
         if (run_head(e, d, HB, q_out, s, true)) return 1;
     }
     if (e->calibrating) e->fp8_calibrated = true;

@@ -56,7 +56,7 @@ class VTAMIQFp8(VTAMIQ):
     def _launch_checked(self, device, launch):
         if self.engine_precision != "fp8":
             return super()._launch_checked(device, launch)
-        launch(self._ensure_engine(device))
+        self._enqueue(device, launch)
         d = self.__dict__
         # the first forward after a (re)load calibrated the activation scales on its batch: remember them, and look at the saturation
         # bit on the first few forwards -- an asynchronous fp8 model must not clamp at +-448 unnoticed

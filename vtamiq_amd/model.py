@@ -366,16 +366,24 @@ class VTAMIQ(nn.Module):
             _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
         return flags.value
 
+    def _enqueue(self, device, launch):
+        """One forward on the engine of the current numerics mode (created / re-packed on demand)."""
+        lib = self._ensure_engine(device)
+        # vtamiq.py:57, 107-108: `token_num` picks the token row the head consumes ("can be CLS token or extra_token"); the reference
+        # reads the attribute at every forward, so does this (a value outside the model's tokens is refused by the library)
+        _lib.check(lib.vtq_set_iqa_token(self._engine, int(self.token_num)))
+        launch(lib)
+
     def _launch_checked(self, device, launch):
         """Enqueue one forward (`launch(lib)`) and apply the model's input / range policy (see DEFAULT_PRECISION)."""
-        launch(self._ensure_engine(device))
+        self._enqueue(device, launch)
         if self.precision == "auto":
             flags = self._read_flags()
             if flags & 2 and not self._auto_fallback:
                 # Either an operand left the fp16 range (the checkpoint's activation scale: bf16x3 cures it, and the switch stays), or
                 # the inputs / weights hold inf / NaN (nothing cures that).  Run the call again in bf16x3 and look.
                 self._auto_fallback = True
-                launch(self._ensure_engine(device))
+                self._enqueue(device, launch)
                 flags2 = self._read_flags()
                 if flags2 & 2:
                     # still non-finite with the fp32 operand range: the DATA is non-finite, not the format too narrow.  Go back to
@@ -384,7 +392,7 @@ class VTAMIQ(nn.Module):
                     self._auto_fallback = False
                     warnings.warn("[VTAMIQ] non-finite scores: the inputs or weights of this call hold inf / NaN (both the fp16x3 and "
                                   "the bf16x3 forward overflowed); the model stays in precision 'fp16x3'")
-                    launch(self._ensure_engine(device))     # the scores handed back are the parity mode's (the healthy pairs' bits included)
+                    self._enqueue(device, launch)            # the scores handed back are the parity mode's (the healthy pairs' bits included)
                     flags2 = (flags2 & 1) | (self._read_flags() & 1)
                 else:
                     warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
