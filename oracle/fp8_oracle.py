@@ -107,14 +107,18 @@ def embeddings(sd: Dict[str, Tensor], spec, patches: Tensor, pos: Tensor, scales
             s8.patch = pick_scale(calib["patch"], s8.patch)
     a8 = quant_act(flat, s8.patch)
     x = linear8(a8, s8.patch, W.reshape(H, -1), sd[e + "patch_embeddings.bias"]).view(B, N, H)
-    table = sd[e + "positional_embeddings.positional_embeddings"][0]
-    x = x + table[vo.pos_index(pos.reshape(B * N, 2), spec.pos_grid)].view(B, N, -1)
+    use_pos = getattr(spec, "use_pos_embedding", True)
+    if use_pos:
+        table = sd[e + "positional_embeddings.positional_embeddings"][0]
+        x = x + table[vo.pos_index(pos.reshape(B * N, 2), spec.pos_grid)].view(B, N, -1)
     if spec.use_scale_embedding:
         if scales is None:
             raise ValueError("Model uses scale embedding but scales is passed as None.")
         st = sd[e + "scale_embeddings.scale_embeddings"][0]
         x = x + st[vo.scale_index(scales.reshape(B * N), spec.num_scales)].view(B, N, -1)
-    cls = sd[e + "cls_token"].expand(B, 1, -1) + table[0]
+    cls = sd[e + "cls_token"].expand(B, 1, -1)
+    if use_pos:
+        cls = cls + table[0]
     toks = [cls]
     if spec.num_extra_tokens > 0:
         toks.append(sd[e + "extra_tokens"].expand(B, spec.num_extra_tokens, -1))
