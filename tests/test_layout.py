@@ -381,3 +381,14 @@ def test_weight_change_detection_is_scoped_to_the_model():
     assert m._signature() == s0 and m.__dict__["_param_cache"] is cache            # same walk object: nothing was invalidated
     m.q_predictor[4] = torch.nn.Linear(192, 1)                                      # a replacement inside THIS model is seen
     assert m._signature() != s0 and m.__dict__["_param_cache"] is not cache
+
+
+def test_integration_doc_quotes_the_current_abi_version():
+    """INTEGRATION.md's stand-alone ctypes stub asserts the ABI version: it must be the header's (it was three versions behind once)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "vtamiq_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    ver = int(re.search(r"#define\s+VTQ_ABI_VERSION\s+(\d+)", hdr).group(1))
+    quoted = [int(v) for v in re.findall(r"vtq_abi_version\(\)\s*==\s*(\d+)", doc)]
+    assert quoted and all(v == ver for v in quoted), (ver, quoted)
