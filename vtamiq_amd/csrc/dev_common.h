@@ -124,6 +124,39 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // an s_nop after every v_exp -- or packs pairs into v_pk_*_f32, which issue slower than what they replace), and the clamp / max
 // are single instructions on the raw MFMA accumulators (as C++ fminf / fmaxf they each get a canonicalising v_max in front).
 // 11 instructions per value.  The GEMM epilogue is bound by vector-instruction issue (profiles/r03_gemm_epilogue_stamps.txt).
+#ifndef VTQ_GELU_PACKED
+#define VTQ_GELU_PACKED 0             // measurement builds: the polynomial as v_pk_fma_f32 (same operations, same bits); profiles/r05_gelu_packed.txt
+#endif
+#if VTQ_GELU_PACKED
+// The same value two at a time: the six polynomial steps and -a q - 1 as seven v_pk_fma_f32 per PAIR, clamp / exp2 / max / last fma as before:
+// 30 instructions per 4 values instead of 44, ONE statement (no compiler-placed nops between its parts).  The pairs live in v[248:255], named
+// as clobbers (an asm operand has no sub-register syntax, and the scalar instructions address the halves): the kernel's allocation becomes 256
+// registers, which the two-waves-per-SIMD GEMMs have.  Constants: the low dword of an SGPR pair, broadcast to both halves by op_sel_hi; made
+// opaque HERE so that they are not materialised above the main loop and kept (spilled) across it.
+__device__ __forceinline__ void gelu_erf4(float (&x)[4]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    uint64_t k0 = 0x37814f5eu, k1 = 0x3a142202u, k2 = 0xbbfaa789u, k3 = 0x3d58c9b9u, k4 = 0x3eeb092fu, k5 = 0x3f935811u, km1 = 0xbf800000u;
+    asm volatile("" : "+s"(k0), "+s"(k1), "+s"(k2), "+s"(k3), "+s"(k4), "+s"(k5), "+s"(km1));
+    const f2 c6 = {-4.525732038018759e-06f, -4.525732038018759e-06f};      // in a register pair: an SGPR beside k0 would be two constant-bus operands
+    float r0, r1, r2, r3;
+    asm("v_min_f32_e64 v248, |%4|, %8\n\tv_min_f32_e64 v249, |%5|, %8\n\tv_min_f32_e64 v250, |%6|, %8\n\tv_min_f32_e64 v251, |%7|, %8\n\t"
+        "v_pk_fma_f32 v[252:253], %16, v[248:249], %9 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], %16, v[250:251], %9 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[252:253], v[248:249], %10 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], v[254:255], v[250:251], %10 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[252:253], v[248:249], %11 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], v[254:255], v[250:251], %11 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[252:253], v[248:249], %12 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], v[254:255], v[250:251], %12 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[252:253], v[248:249], %13 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], v[254:255], v[250:251], %13 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[252:253], v[248:249], %14 op_sel_hi:[1,1,0]\n\tv_pk_fma_f32 v[254:255], v[254:255], v[250:251], %14 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 v[252:253], v[248:249], v[252:253], %15 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[254:255], v[250:251], v[254:255], %15 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_exp_f32_e32 v252, v252\n\tv_exp_f32_e32 v253, v253\n\tv_exp_f32_e32 v254, v254\n\tv_exp_f32_e32 v255, v255\n\t"
+        "v_max_f32_e32 v248, 0, %4\n\tv_max_f32_e32 v249, 0, %5\n\tv_max_f32_e32 v250, 0, %6\n\tv_max_f32_e32 v251, 0, %7\n\t"
+        "v_fma_f32 %0, -|%4|, v252, v248\n\tv_fma_f32 %1, -|%5|, v253, v249\n\tv_fma_f32 %2, -|%6|, v254, v250\n\tv_fma_f32 %3, -|%7|, v255, v251"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(5.7f), "s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(km1), "v"(c6)
+        : "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    x[0] = r0; x[1] = r1; x[2] = r2; x[3] = r3;
+}
+#else
 __device__ __forceinline__ void gelu_erf4(float (&x)[4]) {
     float t0, t1, t2, t3, q0, q1, q2, q3;
     const float c6 = -4.525732038018759e-06f, c57 = 5.7f;
@@ -142,6 +175,7 @@ __device__ __forceinline__ void gelu_erf4(float (&x)[4]) {
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(c6), "s"(c57));       // c6 in a VGPR: an SGPR beside the literal would be two constant-bus operands
     x[0] = q0; x[1] = q1; x[2] = q2; x[3] = q3;
 }
+#endif
 
 // hi = RNE(v), lo = RNE(v - hi) for FOUR values of the f16 format in 6 instructions: two v_cvt_pk_f16_f32, then
 // lo = fma(v, 1.0, -hi) by v_fma_mixlo / mixhi_f16 with hi read from its f16 half (computed in fp32, rounded once) -- bit for bit

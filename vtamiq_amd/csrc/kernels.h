@@ -41,6 +41,7 @@ inline bool num_valid(Num n) {
 //   VTQ_SW_NOFILL / NOMFMA / NOSTORE / NOQ / NODMA / PAIRED / DIST / HALFREADS   attention.hip pipelined kernel: skeleton ablations, read-ahead distance
 //   VTQ_SW_SEAM_STAGGER=n attention.hip: every second workgroup of an XCD starts n us late (profiles/r05_attention_seams.txt)
 //   VTQ_LIBM_ERF          dev_common.h: erff() instead of the fitted exact-erf GELU (accuracy cross-check)
+//   VTQ_GELU_PACKED=1     dev_common.h: the GELU polynomial as v_pk_fma_f32 (same bits, 30 instead of 44 instructions per 4 values; equal time: profiles/r05_gelu_packed.txt)
 //
 // Measurement knobs.  The PRODUCT library reads no environment variable and executes no measurement branch: every knob below exists only
 // in builds with -DVTQ_MEASURE (tools/build_abl.sh), where VTQ_MEASURE_ENV is getenv; in the shipped build it is a null constant (the
