@@ -14,7 +14,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //      2: v_pk_mul_f32   3: v_pk_add_f32   4: v_fmaak_f32 (literal constant, the shipped polynomial's form)   5: v_exp_f32
 //      6: mixed as the shipped gelu_erf4 (per 4 values: 4 min, 24 fmaak, 4 fma, 4 exp, 4 max, 4 fma)   7: the same with the polynomial packed
 template <int KIND>
-__global__ __launch_bounds__(512) void k(unsigned long long* cyc, float* out, int reps) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* cyc, float* out, int reps) {
     float v[32];
     for (int i = 0; i < 32; ++i) v[i] = 0.5f + 1e-3f * ((threadIdx.x + 7 * i) & 63);
     f32x2 p[16];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long* cyc, float* out, in
 }
 
 template <int KIND> void run(const char* name, int values_per_rep, int instr_per_rep, unsigned long long* dcyc, float* dout) {
-    for (int threads : {256, 512}) {                     // one / two waves per SIMD
+    for (int threads : {256, 512, 1024}) {               // one / two / four waves per SIMD
         const int wgs = 256, waves = wgs * threads / 64, reps = 64;
         hipLaunchKernelGGL((k<KIND>), dim3(wgs), dim3(threads), 0, 0, dcyc, dout, reps);
         hipLaunchKernelGGL((k<KIND>), dim3(wgs), dim3(threads), 0, 0, dcyc, dout, reps);
@@ -123,7 +123,7 @@ template <int KIND> void run(const char* name, int values_per_rep, int instr_per
 
 int main() {
     unsigned long long* dcyc; float* dout;
-    (void)hipMalloc(&dcyc, 256 * 8 * 8); (void)hipMalloc(&dout, 256 * 512 * 4);
+    (void)hipMalloc(&dcyc, 256 * 16 * 8); (void)hipMalloc(&dout, 256 * 1024 * 4);
     run<0>("v_fma_f32 (32 per rep)", 32, 32, dcyc, dout);
     run<4>("v_fmaak_f32 literal (32 per rep)", 32, 32, dcyc, dout);
     run<1>("v_pk_fma_f32 (16 per rep)", 32, 16, dcyc, dout);
