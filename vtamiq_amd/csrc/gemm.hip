@@ -62,6 +62,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef VTQ_EPI_BALANCED
+#define VTQ_EPI_BALANCED 1            // 0: the plane-alternating passes of rounds 2 - 4 (A/B: profiles/r05_epilogue_balanced.txt)
+#endif
+
 constexpr int kHalfRows = 128;
 
 // ---- shared epilogue of the ping-pong kernels -------------------------------------------------------------------------
@@ -180,6 +184,81 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         }
         copy_out(NPASS - 1);
         fp8_report(p.obs, amax8, p.out_scale);
+#if VTQ_EPI_BALANCED
+    } else if constexpr ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && OPL == 2) {
+        // Two output planes, BALANCED passes (round 5): chunk (mh, mi) = the 32 rows {mh*128 + wr*64 + mi*16 + fr} with BOTH planes per pass --
+        // image = [plane][row wr*16 + fr][256 x 16 bit + pad] -- so that every barrier interval holds the same work (the form below alternates a pass
+        // with all of a chunk's arithmetic and a pass that only writes the kept lo plane, and needs 16 registers for that plane).  Within an
+        // interval every wave ISSUES the LDS reads of the previous chunk's copy-out, converts the next chunk under them, then waits and stores:
+        // the read latency sits under the conversion and both waves of a SIMD convert at the same time (two waves issue vector instructions
+        // every 3.3 cycles, a lone one every 6.6: profiles/r05_gelu_packed.txt section 1).  Same values, same stores per thread.
+        constexpr int RS = 528;
+        constexpr int IMG = 64 * RS;                    // 2 planes x 32 rows
+        constexpr int NPASS = MH * 4;
+        auto convert = [&](int pass) {
+            const int mh = pass >> 2, mi = pass & 3;
+            char* img = smem + STG + (pass & 1) * IMG;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int lrow = wr * 16 + fr;
+                    const int col = nh * 128 + wc * 32 + ni * 16 + fq * 4;
+                    const f32x4 a = acc[mh][nh][mi][ni];
+                    float v[4] = {a[0], a[1], a[2], a[3]};
+                    if constexpr (!BIASED) {
+                        const float4 bb = b4[nh][ni];
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    if constexpr (EPI == EPI_BIAS_GELU) gelu_erf4(v);
+                    tx4 h, l;
+                    if constexpr (std::is_same<T, f16>::value) {
+                        split4_f16(v, h, l);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { T x, y; split2<T>(v[k], x, y); h[k] = x; l[k] = y; }
+                    }
+                    *(tx4*)(img + lrow * RS + col * 2) = h;
+                    *(tx4*)(img + (32 + lrow) * RS + col * 2) = l;
+                }
+        };
+        const int c16 = tid & 31, r0 = tid >> 5;
+        u32x4 cv[4];                                    // image rows r0, 16 + r0 of plane 0, then of plane 1 (16 * RS apart)
+        auto copy_issue = [&](int pass) {               // hidden from hipcc's waitcnt bookkeeping (see lds_read_rows4); copy_store waits
+            const char* img = smem + STG + (pass & 1) * IMG;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%c5\n\tds_read_b128 %2, %4 offset:%c6\n\tds_read_b128 %3, %4 offset:%c7"
+                         : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3])
+                         : "v"(lds_addr(img + r0 * RS + c16 * 16)), "i"(16 * RS), "i"(32 * RS), "i"(48 * RS) : "memory");
+        };
+        auto copy_store = [&](int pass) {
+            const int mh = pass >> 2, mi = pass & 3;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]) :: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {               // k = plane * 2 + wr
+                const int grow = mh * 128 + (k & 1) * 64 + mi * 16 + r0;
+                T* og = (T*)p.out + (k >> 1) * p.o_plane + (m0 + grow) * p.ldo + n0 + c16 * 8;
+                store_nt16(og, uint4{cv[k][0], cv[k][1], cv[k][2], cv[k][3]});
+            }
+        };
+        VTQ_EPI_T0()
+        convert(0);
+        VTQ_EPI_T1(conv)
+        interval_end();
+        VTQ_EPI_T1(wait)
+#pragma unroll
+        for (int pass = 1; pass < NPASS; ++pass) {
+            copy_issue(pass - 1);
+            convert(pass);
+            VTQ_EPI_T1(conv)
+            copy_store(pass - 1);
+            VTQ_EPI_T1(copy)
+            interval_end();
+            VTQ_EPI_T1(wait)
+        }
+        copy_issue(NPASS - 1);
+        copy_store(NPASS - 1);
+        VTQ_EPI_T1(copy)
+#endif
     } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // chunk (mh, q): the 64 rows {mh*128 + wr*64 + (2q + e)*16 + fr}, image row = wr*32 + e*16 + fr; one pass per plane
         constexpr int RS = 528;                         // 256 x 16 bit + 16 B pad: rows stay 16-B aligned for ds_read_b128
