@@ -65,6 +65,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 #ifndef VTQ_EPI_WAVE
 #define VTQ_EPI_WAVE 0                // 1: wave-private staging of the two-plane bias / GELU epilogue, no workgroup barrier inside it (A/B: profiles/r05_epilogue_wave.txt)
 #endif
+#ifndef VTQ_RESID_DEFER
+#define VTQ_RESID_DEFER 0             // 1: residual epilogue with the copy-out's LDS reads issued before the next chunk's conversion (A/B: profiles/r05_epilogue_balanced.txt)
+#endif
 #ifndef VTQ_EPI_BALANCED
 #define VTQ_EPI_BALANCED 1            // 0: the plane-alternating passes of rounds 2 - 4 (A/B: profiles/r05_epilogue_balanced.txt)
 #endif
@@ -467,10 +470,23 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) xv[ch & 1][ps] = *(const float4*)(xg + (int64_t)grow_of(ch, ps) * p.N);
         };
-        auto copy_out = [&](int ch) {
+        f32x4 dv[4];
+#if VTQ_RESID_DEFER
+        // the previous chunk's image rows are requested BEFORE the next chunk's conversion and waited for behind it (as in the balanced two-plane form)
+        auto copy_issue = [&](int ch) {
             const char* img = smem + STG + (ch & 1) * IMG;
-            f32x4 dv[4];
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%c5\n\tds_read_b128 %2, %4 offset:%c6\n\tds_read_b128 %3, %4 offset:%c7"
+                         : "=&v"(dv[0]), "=&v"(dv[1]), "=&v"(dv[2]), "=&v"(dv[3])
+                         : "v"(lds_addr(img + r0 * RS + c16 * 16)), "i"(8 * RS), "i"(16 * RS), "i"(24 * RS) : "memory");
+        };
+#endif
+        auto copy_out = [&](int ch) {
+#if VTQ_RESID_DEFER
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]) :: "memory");
+#else
+            const char* img = smem + STG + (ch & 1) * IMG;
             lds_read_rows4<8 * RS>(img + r0 * RS + c16 * 16, dv);
+#endif
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {            // image row ps*8 + r0 = (wr = ps>>1, fr = (ps&1)*8 + r0)
                 float4 x = xv[ch & 1][ps];
@@ -503,10 +519,19 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) {
             load_x(ch);
+#if VTQ_RESID_DEFER
+            copy_issue(ch - 1);
+            convert(ch);
+            copy_out(ch - 1);
+#else
             copy_out(ch - 1);
             convert(ch);
+#endif
             interval_end();
         }
+#if VTQ_RESID_DEFER
+        copy_issue(NCH - 1);
+#endif
         copy_out(NCH - 1);
     } else {  // EPI_EMBED: scattered rows + table gathers, once per forward: direct from registers
 #pragma unroll
