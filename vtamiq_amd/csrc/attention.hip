@@ -456,6 +456,9 @@ struct PPFrags {                      // DIST + 1 rolling fragment buffers: grou
 #ifndef VTQ_SW_NOFILL
 #define VTQ_SW_NOFILL 0
 #endif
+#ifndef VTQ_SW_PRIO
+#define VTQ_SW_PRIO 0                 // measurement builds: issue priority alternating between the two waves of a SIMD (1: per phase, 2: per fragment group, 3: static for waves 4-7)
+#endif
 #ifndef VTQ_SW_NOSTORE
 #define VTQ_SW_NOSTORE 0
 #endif
@@ -922,6 +925,16 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         const f4 w = {v[o], v[o + 1], v[o + 2], v[o + 3]};
         return __builtin_bit_cast(tx8, w);
     };
+    // Issue priority of this wave against its SIMD partner (waves w and w + 4 share a SIMD; the older one, w, wins arbitration by age): the stamps show
+    // waves 4 - 7 taking 2 462 + 3 312 cycles for the two phases of a tile against 1 674 + 2 837 for waves 0 - 3, which then wait 1 300 cycles longer at the
+    // tile's barrier (profiles/r05_attention_prio.txt).  hi(x): this wave is favoured in slot x (phase or fragment group).
+    auto prio = [&](int slot) __attribute__((always_inline)) {
+#if VTQ_SW_PRIO == 1 || VTQ_SW_PRIO == 2
+        if (((wave >> 2) ^ slot) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#elif VTQ_SW_PRIO == 3
+        if (wave >> 2) __builtin_amdgcn_s_setprio(2);
+#endif
+    };
     auto iteration = [&](auto more_c, int tau) __attribute__((always_inline)) {
         constexpr bool more = decltype(more_c)::value;         // is there a tile tau + 1 (its QK^T and softmax run in this iteration)
         const int tb_next = (ct + 1 == nt) ? 0 : ct + 1;       // its index in its block
@@ -940,6 +953,9 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         // Q of the block after the one tile tau + 1 belongs to, when tile tau + 1 is that block's last: loaded into spare registers at
         // the top of the iteration whose phase 1 still needs the current Q, installed behind the end-of-iteration wait.
         // ---------------- phase 1: QK^T(tau + 1) -> sB  ||  split of P(tau) = sA, rescale of O ------------------------------
+#if VTQ_SW_PRIO == 1 || VTQ_SW_PRIO == 3
+        prio(1);                                   // phase 1: waves 4 - 7 favoured (1); phase 2: waves 0 - 3 (below)
+#endif
         if (rescale && !wr_pending) {              // a pending block's O is written and cleared below (its successor starts from zero)
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -952,6 +968,9 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             static_for<0, DIST>([&](auto gc) __attribute__((always_inline)) { issue_g(gc, kaddr, vaddr); });
             static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value, sl = g % NS, kb = g >> 2, tt = g & 3;
+#if VTQ_SW_PRIO == 2
+                prio(g);
+#endif
                 issue_g(std::integral_constant<int, g + DIST>{}, kaddr, vaddr);
                 constexpr int ahead = ahead_of(g, 16);
                 if constexpr (NSPLIT == 3) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fr.ka[sl]), "+v"(fr.kl[sl]) : "i"(ahead));
@@ -984,9 +1003,15 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if (seam) { l_fin = l_run; m_run = -1e30f; l_run = 0.f; }
         if constexpr (more) mask_tail(tb_next);
         // ---------------- phase 2: PV(tau) into O  ||  softmax of sB (tile tau + 1) -------------------------------------------
+#if VTQ_SW_PRIO == 1
+        prio(0);
+#endif
         bool sent = false, q_loaded = false;
         auto pv_group = [&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value, sl = (g + 8) % NS, step = g >> 1, d = g & 1;
+#if VTQ_SW_PRIO == 2
+            prio(g);
+#endif
             issue_g(std::integral_constant<int, g + 8 + DIST>{}, kaddr, vaddr);          // nothing beyond group 15
             constexpr int ahead = ahead_of(g + 8, 16);
             if constexpr (NSPLIT == 3)

@@ -42,6 +42,7 @@ inline bool num_valid(Num n) {
 //   VTQ_ATTN_DIAG         attention.hip: per-wave phase stamps (profiles/r03_attention_anatomy.txt)
 //   VTQ_ATTN_NO_VMASK     attention.hip: without the zeroing of masked keys' V rows (profiles/r04_attention_vmask_ab.txt)
 //   VTQ_SW_NOFILL / NOMFMA / NOSTORE / NOQ / NODMA / PAIRED / DIST / HALFREADS   attention.hip pipelined kernel: skeleton ablations, read-ahead distance
+//   VTQ_SW_PRIO=1|2|3     attention.hip: s_setprio alternating between the two waves of a SIMD per phase / per fragment group / static for waves 4-7 (profiles/r05_attention_prio.txt)
 //   VTQ_SW_SEAM_STAGGER=n attention.hip: every second workgroup of an XCD starts n us late (profiles/r05_attention_seams.txt)
 //   VTQ_LIBM_ERF          dev_common.h: erff() instead of the fitted exact-erf GELU (accuracy cross-check)
 //   VTQ_GELU_PACKED=1     dev_common.h: the GELU polynomial as v_pk_fma_f32 (same bits, 30 instead of 44 instructions per 4 values; equal time: profiles/r05_gelu_packed.txt)
