@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the variant lives in commit dbe3f8f; it was removed from the tree after this measurement)
 # A/B: wave-private staging of the two-plane bias / GELU epilogue (no workgroup barrier inside the epilogue; -DVTQ_EPI_WAVE=1) against the shipped
 # balanced passes.  Same bits.  Tests on the variant first, then interleaved timing on one box.
 cd "$(dirname "$0")/../.."

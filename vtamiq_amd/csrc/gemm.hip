@@ -62,9 +62,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-#ifndef VTQ_EPI_WAVE
-#define VTQ_EPI_WAVE 0                // 1: wave-private staging of the two-plane bias / GELU epilogue, no workgroup barrier inside it (A/B: profiles/r05_epilogue_wave.txt)
-#endif
 #ifndef VTQ_RESID_DEFER
 #define VTQ_RESID_DEFER 0             // 1: residual epilogue with the copy-out's LDS reads issued before the next chunk's conversion (A/B: profiles/r05_epilogue_balanced.txt)
 #endif
@@ -190,80 +187,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
         }
         copy_out(NPASS - 1);
         fp8_report(p.obs, amax8, p.out_scale);
-#if VTQ_EPI_WAVE
-    } else if constexpr ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && OPL == 2) {
-        // Two output planes, WAVE-PRIVATE staging (round 5): no workgroup barrier inside the epilogue.  A wave holds, of chunk (mh, mi) = the 16 rows
-        // {mh*128 + wr*64 + mi*16 + fr}, the 64 columns {nh*128 + wc*32 + ni*16 + fq*4 + 0..3}: per row and plane two 64-byte pieces.  It transposes them through
-        // ITS OWN 2 x 4 KB of LDS -- image [plane][row fr][8 chunks of 16 B], chunk index cc = nh*4 + ni*2 + (fq >> 1) XORed with g(fr) = ((fr >> 1) & 1) * 4 +
-        // (fr >> 2): 8-byte writes and 16-byte reads are both conflict-free -- and reads back 16 B per lane, lane = 4 * row + quarter, so that a store
-        // instruction writes sixteen whole 64-byte pieces.  LDS operations of one wave execute in order: the reads of a chunk follow its writes
-        // without a wait, are issued before the next chunk's conversion and waited for behind it.  The waves of a workgroup drift apart freely:
-        // one's stores and LDS traffic run under another's vector work (a lone wave issues a vector instruction only every 6.6 cycles,
-        // profiles/r05_gelu_packed.txt section 1).  Same values, same 32 stores per thread.
-        constexpr int NCH = MH * 4;
-        const int wave_id = wr * 4 + wc;
-        const int lane = tid & 63;
-        const int g_w = ((fr >> 1) & 1) * 4 + (fr >> 2);
-        const int pc = lane >> 2, qt = lane & 3;
-        const int g_r = ((pc >> 1) & 1) * 4 + (pc >> 2);
-        char* const wbuf = smem + STG + wave_id * 8192;
-        auto convert = [&](int ch) {
-            const int mh = ch >> 2, mi = ch & 3;
-            char* img = wbuf + (ch & 1) * 4096 + fr * 128 + (fq & 1) * 8;
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const f32x4 a = acc[mh][nh][mi][ni];
-                    float v[4] = {a[0], a[1], a[2], a[3]};
-                    if constexpr (!BIASED) {
-                        const float4 bb = b4[nh][ni];
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    if constexpr (EPI == EPI_BIAS_GELU) gelu_erf4(v);
-                    tx4 h, l;
-                    if constexpr (std::is_same<T, f16>::value) {
-                        split4_f16(v, h, l);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { T x, y; split2<T>(v[k], x, y); h[k] = x; l[k] = y; }
-                    }
-                    const int cc = (nh * 4 + ni * 2 + (fq >> 1)) ^ g_w;
-                    *(tx4*)(img + cc * 16) = h;
-                    *(tx4*)(img + 2048 + cc * 16) = l;
-                }
-        };
-        u32x4 cv[4];                                    // (plane, nh) = (j >> 1, j & 1): row pc, columns nh*128 + wc*32 + qt*8 .. + 7
-        auto copy_issue = [&](int ch) {                 // hidden from hipcc's waitcnt bookkeeping; copy_store waits
-            const uint32_t base = lds_addr(wbuf + (ch & 1) * 4096 + pc * 128);
-            const uint32_t a0 = base + (uint32_t)(((0 * 4 + qt) ^ g_r) << 4), a1 = base + (uint32_t)(((1 * 4 + qt) ^ g_r) << 4);
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %5 offset:2048"
-                         : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]) : "v"(a0), "v"(a1) : "memory");
-        };
-        auto copy_store = [&](int ch) {
-            const int mh = ch >> 2, mi = ch & 3;
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]) :: "memory");
-            const int grow = mh * 128 + wr * 64 + mi * 16 + pc;
-            T* og = (T*)p.out + (m0 + grow) * p.ldo + n0 + wc * 32 + qt * 8;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                store_nt16(og + (j >> 1) * p.o_plane + (j & 1) * 128, uint4{cv[j][0], cv[j][1], cv[j][2], cv[j][3]});
-        };
-        VTQ_EPI_T0()
-        convert(0);
-        copy_issue(0);
-        VTQ_EPI_T1(conv)
-#pragma unroll
-        for (int ch = 1; ch < NCH; ++ch) {
-            convert(ch);
-            VTQ_EPI_T1(conv)
-            copy_store(ch - 1);
-            copy_issue(ch);
-            VTQ_EPI_T1(copy)
-        }
-        copy_store(NCH - 1);
-        VTQ_EPI_T1(copy)
-#endif
 #if VTQ_EPI_BALANCED
     } else if constexpr ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && OPL == 2) {
         // Two output planes, BALANCED passes (round 5): chunk (mh, mi) = the 32 rows {mh*128 + wr*64 + mi*16 + fr} with BOTH planes per pass --

@@ -33,7 +33,6 @@ inline bool num_valid(Num n) {
 //   VTQ_GEMM_DIAG         gemm.hip: s_memtime / s_memrealtime stamps around K loops, kernel and epilogue steps; shadow-VALU filler (profiles/r03_clock.txt)
 //   VTQ_EPI_ABL=1..4      gemm.hip epilogue ablations: 1 no GELU arithmetic, 2 no copy-out, 3 no global stores, 4 no LDS staging (r03_gemm_epilogue_ablation.txt)
 //   VTQ_EPI_ORDER=1|2     gemm.hip: both wave groups copy first / convert first in an epilogue interval (the plane-alternating form only)
-//   VTQ_EPI_WAVE=1        gemm.hip: wave-private staging of that epilogue, no workgroup barrier inside it (bit-identical, +2.3 % on fc1: profiles/r05_epilogue_wave.txt)
 //   VTQ_RESID_DEFER=1     gemm.hip: residual epilogue with the copy-out's LDS reads issued before the next chunk's conversion (equal: profiles/r05_epilogue_balanced.txt)
 //   VTQ_EPI_BALANCED=0    gemm.hip: the plane-alternating passes of the two-plane bias / GELU epilogue (rounds 2 - 4) instead of the balanced ones (profiles/r05_epilogue_balanced.txt)
 //   VTQ_RESID_PLANES      gemm.hip: pricing build of a LayerNorm fold's producer side (profiles/r03_ln_fold_price.txt)
