@@ -40,41 +40,10 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-#ifndef VTQ_P_SPLIT_RTZ
-#define VTQ_P_SPLIT_RTZ 0             // 1: the fp16 P split of rounds 1 - 5a (hi by truncation, lo = RTZ(p - hi): 6 vector instructions per pair; A/B: profiles/r05_attention_psplit.txt)
-#endif
-// fp16 hi / lo split of FOUR probabilities in 6 vector instructions (dev_common.h split4_f16: hi = RNE(p), lo = RNE(p - hi) by v_fma_mixlo / mixhi_f16 reading hi
-// from its f16 half) instead of 12 (truncating conversion, two back-conversions, two subtractions, truncating conversion per pair).  Both attention kernels use it, so
-// they stay bit-identical to each other.  The leading s_nop: the statement's first instruction may read a v_exp_f32 result (4-wave kernel: the split follows the
-// exponentials), and hipcc pads the transcendental -> vector-use window only for instructions it emits itself, not for asm operands -- round 3's inline v_fma_mix
-// form without it produced rare wrong lo halves.
-#define VTQ_P_SPLIT_BODY                                                        \
-        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"                                       \
-        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"                                       \
-        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"                \
-        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"                \
-        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
-        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-template <bool AFTER_EXP>              // AFTER_EXP: the values may come straight from v_exp_f32 (4-wave kernel); the pipelined kernel splits a tile's P an iteration later
-__device__ __forceinline__ void split_p4_f16(const float (&v)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
-    if constexpr (AFTER_EXP)
-        asm("s_nop 1\n\t" VTQ_P_SPLIT_BODY : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-    else
-        asm(VTQ_P_SPLIT_BODY : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-}
-
 // Split 8 probabilities into the hi / lo MFMA fragments (element j of the fragment = p[j]).
 template <typename T>
 __device__ __forceinline__ void split_p8(const float (&p)[8], typename Vec<T>::x8& hi, typename Vec<T>::x8& lo) {
-    if constexpr (std::is_same<T, f16>::value && !VTQ_P_SPLIT_RTZ) {
-        uint32_t hw[4], lw[4];
-        const float a[4] = {p[0], p[1], p[2], p[3]}, b[4] = {p[4], p[5], p[6], p[7]};
-        split_p4_f16<true>(a, hw[0], hw[1], lw[0], lw[1]);
-        split_p4_f16<true>(b, hw[2], hw[3], lw[2], lw[3]);
-        typedef __attribute__((ext_vector_type(4))) uint32_t u4;
-        hi = __builtin_bit_cast(f16x8, u4{hw[0], hw[1], hw[2], hw[3]});
-        lo = __builtin_bit_cast(f16x8, u4{lw[0], lw[1], lw[2], lw[3]});
-    } else if constexpr (std::is_same<T, f16>::value) {
+    if constexpr (std::is_same<T, f16>::value) {
         typedef __attribute__((ext_vector_type(2))) _Float16 h2;
         uint32_t hw[4], lw[4];
 #pragma unroll
@@ -520,9 +489,7 @@ __device__ __forceinline__ f32x16 SW_MFMA(typename Vec<T>::x8 a, typename Vec<T>
 
 template <typename T>
 __device__ __forceinline__ void split_p4(const float (&p)[4], uint32_t (&hw)[2], uint32_t (&lw)[2]) {
-    if constexpr (std::is_same<T, f16>::value && !VTQ_P_SPLIT_RTZ) {
-        split_p4_f16<false>(p, hw[0], hw[1], lw[0], lw[1]);
-    } else if constexpr (std::is_same<T, f16>::value) {
+    if constexpr (std::is_same<T, f16>::value) {
         typedef __attribute__((ext_vector_type(2))) _Float16 h2;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
