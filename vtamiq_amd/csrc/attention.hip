@@ -583,21 +583,12 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     dg_t = dg_k0;
 #endif
 
-#ifndef VTQ_SW_REVERSE
-#define VTQ_SW_REVERSE 0              // 1: the block list is walked from the LAST sequence to the first (the rows the QKV GEMM wrote last are read first)
-#endif
     auto block_base = [&](int b, int& qb) __attribute__((always_inline)) -> int64_t {
-#if VTQ_SW_REVERSE
-        { const int pr = b / nqb; b = (nblk / nqb - 1 - pr) * nqb + (b - pr * nqb); }     // (sequence, head) pairs reversed, the query blocks of a pair in order
-#endif
         qb = b % nqb;
         const int head = (b / nqb) % nh, seq = b / (nqb * nh);
         return (int64_t)seq * S_pad * ld + head * 64;
     };
     auto block_out = [&](int b) __attribute__((always_inline)) -> int64_t {
-#if VTQ_SW_REVERSE
-        { const int pr = b / nqb; b = (nblk / nqb - 1 - pr) * nqb + (b - pr * nqb); }
-#endif
         const int head = (b / nqb) % nh, seq = b / (nqb * nh);
         return (int64_t)seq * S_pad * H + head * 64;
     };

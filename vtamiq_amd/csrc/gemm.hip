@@ -65,9 +65,6 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 #ifndef VTQ_RESID_DEFER
 #define VTQ_RESID_DEFER 0             // 1: residual epilogue with the copy-out's LDS reads issued before the next chunk's conversion (A/B: profiles/r05_epilogue_balanced.txt)
 #endif
-#ifndef VTQ_QKV_CACHED
-#define VTQ_QKV_CACHED 0              // 1: the bias epilogue (QKV) stores with the write-back policy instead of nt (A/B with VTQ_SW_REVERSE: profiles/r05_qkv_cached.txt)
-#endif
 #ifndef VTQ_EPI_BALANCED
 #define VTQ_EPI_BALANCED 1            // 0: the plane-alternating passes of rounds 2 - 4 (A/B: profiles/r05_epilogue_balanced.txt)
 #endif
@@ -243,10 +240,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& p, f32x4 (&acc)[2][2
             for (int k = 0; k < 4; ++k) {               // k = plane * 2 + wr
                 const int grow = mh * 128 + (k & 1) * 64 + mi * 16 + r0;
                 T* og = (T*)p.out + (k >> 1) * p.o_plane + (m0 + grow) * p.ldo + n0 + c16 * 8;
-#if VTQ_QKV_CACHED
-                if constexpr (EPI == EPI_BIAS) *(uint4*)og = uint4{cv[k][0], cv[k][1], cv[k][2], cv[k][3]};      // write-back policy: the consumer reads it from the cache
-                else
-#endif
                 store_nt16(og, uint4{cv[k][0], cv[k][1], cv[k][2], cv[k][3]});
             }
         };
