@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 7
+#define VTQ_ABI_VERSION 8
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -109,6 +109,12 @@ int  vtq_forward(vtq_handle h,
                  const float* pos_ref, const float* pos_dist,
                  const float* scales_ref, const float* scales_dist,
                  int32_t B, int32_t N, float* q_out, void* stream);
+
+/* VTAMIQ.forward on PRE-EMBEDDED input: Embeddings.forward takes the (B, N, H) branch (transformer.py:534-535) -- what a model built with
+ * use_patch_embedding=False is fed, and what the reference does with ANY 3-D `patches` tensor.  feats_*: (B, N, hidden_size) fp32, contiguous; everything
+ * else as vtq_forward.  The patch-embedding weights are not used (they must still be loaded: zeros do). */
+int  vtq_forward_tokens(vtq_handle h, const float* feats_ref, const float* feats_dist, const float* pos_ref, const float* pos_dist,
+                        const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream);
 
 /* Pairwise items (train.predict, train.py:281-301: two model calls sharing the reference image): patches/pos/scales are HOST
  * arrays of 3 DEVICE pointers {ref, dist1, dist2}, each as in vtq_forward (scales may be NULL); the reference image is

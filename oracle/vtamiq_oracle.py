@@ -54,7 +54,7 @@ def embeddings(sd: Dict[str, Tensor], spec, patches: Tensor, pos: Tensor, scales
     """Embeddings.forward + forward_tokens.  transformer.py:507-562."""
     B, N = patches.shape[:2]
     e = "transformer.embeddings."
-    x = patch_embed(sd, patches)
+    x = patch_embed(sd, patches) if patches.dim() == 5 else patches           # (B, N, H) input skips the convolution (transformer.py:527-535)
     use_pos = getattr(spec, "use_pos_embedding", True)
     if use_pos:                                                               # transformer.py:539-543
         table = sd[e + "positional_embeddings.positional_embeddings"][0]      # (G*G+1, H)

@@ -423,6 +423,10 @@ def main():
         run_case("nopos_b2_n40", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_pos_embedding=False, num_extra_tokens=1, num_scales=2)),
                  B=2, N=40, wseed=23, iseed=20)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--preembedded":    # only the use_patch_embedding=False case (added in round 5): (B, N, H) rows as input
+        run_case("preemb_b3_n60", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_patch_embedding=False, num_extra_tokens=2, num_scales=3)),
+                 B=3, N=60, wseed=29, iseed=23, aligned=False)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--token":          # only the token_num case (added in round 5): CLS scores + register-token scores
         run_case("token2_b3_n45", dict(vit_config=dict(variant=B16, num_keep_layers=3, num_extra_tokens=3, use_layer_scale=True)),
                  B=3, N=45, wseed=32, iseed=21, token_num=2)
@@ -463,6 +467,8 @@ def main():
              B=2, N=40, wseed=23, iseed=20)
     run_case("token2_b3_n45", dict(vit_config=dict(variant=B16, num_keep_layers=3, num_extra_tokens=3, use_layer_scale=True)),
              B=3, N=45, wseed=32, iseed=21, token_num=2)
+    run_case("preemb_b3_n60", dict(vit_config=dict(variant=B16, num_keep_layers=2, use_patch_embedding=False, num_extra_tokens=2, num_scales=3)),
+             B=3, N=60, wseed=29, iseed=23, aligned=False)
     run_stress()
     run_ladder()
     run_operating_point()

@@ -11,7 +11,7 @@ from vtamiq_amd.spec import make_spec
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 E2E_CASES = ["c1_b2_n50", "refdefault_b2_n64", "scales3_b2_n40", "unaligned_b3_n50", "c2shape_b4_n500",
-             "vitl_b2_n70", "nocalib_b2_n30", "vitb8_b2_n90", "adapters_b2_n40", "nopos_b2_n40", "token2_b3_n45"]
+             "vitl_b2_n70", "nocalib_b2_n30", "vitb8_b2_n90", "adapters_b2_n40", "nopos_b2_n40", "token2_b3_n45", "preemb_b3_n60"]
 # the reference run on stress_state weights (trained-like statistics: peaked softmax, outlier channels), qk = 3 and 5
 STRESS_CASES = ["stress3_b3_n90", "stress5_b3_n90"]
 

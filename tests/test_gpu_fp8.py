@@ -274,7 +274,7 @@ def test_fp8_patch_embedding_teacher_forced():
     check_f32("embeddings", x, want, 1e-4)
 
 
-FP8_CASES = [c for c in E2E_CASES if c != "adapters_b2_n40"]          # adapters are rejected in the fp8 mode (test below)
+FP8_CASES = [c for c in E2E_CASES if c not in ("adapters_b2_n40", "preemb_b3_n60")]          # adapters are rejected in the fp8 mode (test below)
 
 
 def test_fp8_rejects_adapters():

@@ -81,6 +81,29 @@ def test_token_num_selects_the_iqa_token(precision, options):
     assert np.array_equal(q0, q0b) and np.array_equal(np.concatenate([q2, q2]), q2p)
 
 
+def test_pre_embedded_input():
+    """Embeddings.forward's (B, N, H) branch (transformer.py:527-535): a model WITH the patch convolution handed 3-D rows skips it, like the reference
+    (same weights otherwise: the oracle's scores); a model WITHOUT it handed 5-D patches fails on the missing module, like the reference; the pairwise
+    entry takes patches only."""
+    g, kw, spec, sd, (feats, pos, scales) = load_case("preemb_b3_n60")
+    kw2 = json.loads(json.dumps(kw)); kw2["vit_config"].pop("use_patch_embedding")
+    spec2 = VTAMIQ(**json.loads(json.dumps(kw2)), precision=MAIN).spec
+    sd2 = dict(synth.make_state_dict(spec2, 77))
+    sd2.update(sd)                                           # the golden's weights + a patch convolution that must not matter
+    model = build(kw2, sd2, "auto")
+    p, ps, sc = split_inputs(feats, pos, scales, device=DEV)
+    with torch.no_grad():
+        q, _ = model(p, ps, sc)
+    assert gate(q.cpu().numpy(), g["q"], TOL["fp16x3"]), rel_err(q.cpu().numpy(), g["q"])
+    nopatch = build(kw, sd, MAIN)
+    with torch.no_grad():
+        assert torch.equal(nopatch(p, ps, sc)[0], q)        # the same engine path, the same bits
+        with pytest.raises(AttributeError, match="patch_embeddings"):
+            nopatch((torch.zeros(3, 60, 3, 16, 16, device=DEV),) * 2, ps, sc)
+        with pytest.raises(ValueError):
+            model.forward_pairwise((p[0], p[1], p[1]), (ps[0], ps[1], ps[1]), (sc[0], sc[1], sc[1]))
+
+
 def test_pos_is_not_looked_at_without_positional_embedding():
     """use_pos_embedding=False: the reference never touches `pos` (transformer.py:539), so None, or coordinates that would index past
     the table, give the same scores as the golden's -- bit for bit, and without the IndexError of a model that has a table."""

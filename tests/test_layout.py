@@ -130,8 +130,16 @@ def test_rejected_configs():
     assert m.spec.num_adapters == 2 and sum("adapter" in k for k in m.state_dict()) == 16
     with pytest.raises(ValueError):
         VTAMIQ(vit_config=dict(variant="ViT-H14"))
-    with pytest.raises(NotImplementedError):
-        VTAMIQ(vit_config=dict(variant="ViT-B16", use_patch_embedding=False, pretrained=False))   # pre-embedded input: outside the path
+
+
+def test_model_without_patch_embedding_has_no_convolution():
+    """use_patch_embedding=False (backbone.py:20, transformer.py:473-480): no Conv2d, so no patch_embeddings keys; 5-D input then fails like the
+    reference's missing attribute (the accelerated path takes pre-embedded (B, N, H) rows: tests/test_gpu_parity.py)."""
+    from vtamiq_amd import VTAMIQ
+    m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=1, use_patch_embedding=False, pretrained=False))
+    assert not m.spec.use_patch_embedding and not any("patch_embeddings" in k for k in m.state_dict())
+    assert sorted(m.state_dict()) == sorted(k for k, _, _ in m.spec.state_layout())
+    m.set_freeze_state(True, dict(freeze_dict_vit=None, freeze_quality_decoder=True, freeze_q_predictor=True))
 
 
 def test_model_without_positional_embedding_has_no_table():

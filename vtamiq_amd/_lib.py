@@ -20,7 +20,7 @@ NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
 MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
-ABI_VERSION = 7
+ABI_VERSION = 8
 OPT_FULL_LAST_LAYER = 1
 OPT_FP8_STATIC_SCALES = 2
 OPT_FUSED_LAYERNORM = 4
@@ -49,6 +49,7 @@ SIGNATURES = {
     "vtq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "vtq_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "vtq_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_forward_tokens": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_forward_pairwise": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -137,6 +137,29 @@ __global__ void embed_index_kernel(ImgPtrs pos, ImgPtrs sc, int nimg, int* __res
     row_map[r] = (int)seq_row(sm, img * B + b) + T + n;
 }
 
+// Embeddings.forward on PRE-EMBEDDED input (transformer.py:534-535: a (B, N, H) tensor skips the patch convolution): token row = feature row + positional
+// row + scale row, in the reference's order of additions (:540-552); the destinations and table indices are embed_index_kernel's.
+__global__ __launch_bounds__(256) void embed_rows_kernel(ImgPtrs feats, int nimg, int BN, const int* __restrict__ row_map, const int* __restrict__ pidx,
+                                                         const int* __restrict__ sidx, const float* __restrict__ table1,
+                                                         const float* __restrict__ table2, float* __restrict__ x, int H4) {
+    const int r = blockIdx.x;
+    const int img = r / BN, rr = r - img * BN;
+    const float* fb = img == 0 ? feats.p[0] : (img == 1 ? feats.p[1] : feats.p[2]);
+    const float4* src = (const float4*)(fb + (int64_t)rr * H4 * 4);
+    const int orow = row_map[r];
+    if (orow < 0) return;
+    const float4* t1 = (const float4*)table1 + (int64_t)pidx[r] * H4;
+    const float4* t2 = table2 ? (const float4*)table2 + (int64_t)sidx[r] * H4 : nullptr;
+    float4* dst = (float4*)x + (int64_t)orow * H4;
+    for (int c = threadIdx.x; c < H4; c += blockDim.x) {
+        float4 v = src[c];
+        const float4 a = t1[c];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        if (t2) { const float4 b = t2[c]; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        dst[c] = v;
+    }
+}
+
 // Embeddings.forward_tokens (transformer.py:507-524): row 0 = cls + pos_table[0]; rows 1..T-1 = register tokens.
 __global__ void tokens_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos_table,
                               const float* __restrict__ extra, SeqMap sm, int T, int H) {
@@ -330,6 +353,13 @@ hipError_t launch_embed_index(const float* const* pos, const float* const* sc, i
     ImgPtrs sp{{sc ? sc[0] : nullptr, sc ? sc[1] : nullptr, (sc && nimg > 2) ? sc[2] : nullptr}};
     hipLaunchKernelGGL(embed_index_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, s, pp, sp, nimg, pidx, sidx, row_map, B, N, rows_pad,
                        sm, T, grid, num_scales, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_rows(const float* const* feats, int nimg, int BN, const int* row_map, const int* pidx, const int* sidx,
+                             const float* table1, const float* table2, float* x, int H, hipStream_t s) {
+    ImgPtrs fp{{feats[0], feats[1], nimg > 2 ? feats[2] : nullptr}};
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(nimg * BN), dim3(256), 0, s, fp, nimg, BN, row_map, pidx, sidx, table1, table2, x, H / 4);
     return hipGetLastError();
 }
 

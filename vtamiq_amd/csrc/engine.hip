@@ -918,8 +918,9 @@ int vtq_profile_collect(vtq_handle e, double* ms_sum, int64_t* launches) {
 
 // nimg = 2: q_out[B] for (ref, dist); nimg = 3: q_out[2B] = scores of (ref, dist1) then (ref, dist2) with ref encoded once
 static int forward_impl(vtq_handle e, int nimg, const float* const* patches, const float* const* pos, const float* const* scales,
-                        int32_t B, int32_t N, float* q_out, void* stream) {
+                        int32_t B, int32_t N, float* q_out, void* stream, bool tokens_in = false) {
     if (!e) return fail("vtq_forward: null handle");
+    if (tokens_in && e->fp8) return fail("vtq_forward_tokens: the fp8 experiment has no pre-embedded input path");
     for (int k = 0; k < nimg; ++k)
         if (!patches[k] || !pos[k]) return fail("vtq_forward: null tensor");
     if (!q_out) return fail("vtq_forward: null output");
@@ -952,6 +953,15 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
     }
 
     // ---- embeddings (transformer.py:526-562) -------------------------------------------------------------------
+    if (tokens_in) {
+        // pre-embedded input (transformer.py:534-535): `patches` are (B, N, H) feature rows; no patch convolution
+        Prof p(e, s, VTQ_K_CONVERT);
+        HIP_TRY(launch_embed_index(pos, use_scales ? scales : nullptr, nimg, e->pidx, e->sidx, e->row_map, B, N, (int)g.P_pad, g.sm, T,
+                                   c.pos_grid, c.num_scales, e->err_flag, s));
+        HIP_TRY(launch_zero_pad_rows(e->x, g.nseq, g.S, g.sm, H, (int)g.rows_alloc, s));
+        HIP_TRY(launch_tokens(e->x, e->cls, e->pos_table, e->extra, g.nseq, g.sm, T, H, s));
+        HIP_TRY(launch_embed_rows(patches, nimg, B * N, e->row_map, e->pidx, e->sidx, e->pos_table, use_scales ? e->scale_table : nullptr, e->x, H, s));
+    } else {
     {
         Prof p(e, s, VTQ_K_CONVERT);
         if (e->fp8) {
@@ -973,6 +983,7 @@ static int forward_impl(vtq_handle e, int nimg, const float* const* patches, con
         a.idx2 = e->sidx; a.table2 = use_scales ? e->scale_table : nullptr;
         a.wscale = e->spatch; a.ascale_inv = 1.0f / e->s_patch;
         HIP_TRY(launch_gemm(a, e->lin, EPI_EMBED, s));
+    }
     }
     if (e->trace) HIP_TRY(launch_copy_tokens(e->x, e->trace, g.nseq, g.sm, T, H, s));
 
@@ -1057,6 +1068,14 @@ int vtq_forward(vtq_handle e, const float* patches_ref, const float* patches_dis
     const float* ps[2] = {pos_ref, pos_dist};
     const float* sc[2] = {scales_ref, scales_dist};
     return forward_impl(e, 2, p, ps, sc, B, N, q_out, stream);
+}
+
+int vtq_forward_tokens(vtq_handle e, const float* feats_ref, const float* feats_dist, const float* pos_ref, const float* pos_dist,
+                       const float* scales_ref, const float* scales_dist, int32_t B, int32_t N, float* q_out, void* stream) {
+    const float* p[2] = {feats_ref, feats_dist};
+    const float* ps[2] = {pos_ref, pos_dist};
+    const float* sc[2] = {scales_ref, scales_dist};
+    return forward_impl(e, 2, p, ps, sc, B, N, q_out, stream, true);
 }
 
 int vtq_forward_pairwise(vtq_handle e, const float* const* patches, const float* const* pos, const float* const* scales, int32_t B,

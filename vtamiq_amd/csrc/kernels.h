@@ -162,6 +162,9 @@ hipError_t launch_embed_index(const float* const* pos, const float* const* sc, i
                               int rows_pad, SeqMap sm, int T, int grid, int num_scales, int* err, hipStream_t s);
 
 // CLS (+pos row 0) and register tokens into the first T rows of every sequence
+// pre-embedded input (transformer.py:534-535): x[row_map[r]] = feats[r] + table1[pidx[r]] (+ table2[sidx[r]]); feats: nimg pointers to (B*N, H) fp32
+hipError_t launch_embed_rows(const float* const* feats, int nimg, int BN, const int* row_map, const int* pidx, const int* sidx,
+                             const float* table1, const float* table2, float* x, int H, hipStream_t s);
 hipError_t launch_tokens(float* x, const float* cls, const float* pos_table, const float* extra, int nseq, SeqMap sm,
                          int T, int H, hipStream_t s);
 

@@ -61,7 +61,9 @@ class _Embeddings(_Params):                 # Embeddings (transformer.py:458-505
     def __init__(self, spec: ModelSpec):
         super().__init__()
         H, P = spec.hidden_size, spec.patch_size
-        self.patch_embeddings = nn.Conv2d(3, H, kernel_size=P, stride=P)
+        if spec.use_patch_embedding:
+            self.patch_embeddings = nn.Conv2d(3, H, kernel_size=P, stride=P)
+        self.use_patch_embedding = spec.use_patch_embedding
         self.cls_token = nn.Parameter(torch.zeros(1, 1, H).normal_(std=0.02))
         if spec.num_extra_tokens > 0:
             self.extra_tokens = nn.Parameter(torch.zeros(1, spec.num_extra_tokens, H).normal_(std=0.02))
@@ -244,7 +246,7 @@ class VTAMIQ(nn.Module):
             tr.embeddings.cls_token.requires_grad = requires_grad
         if (freeze_all or fd["freeze_embeddings_extra_tokens"]) and hasattr(tr.embeddings, "extra_tokens"):
             tr.embeddings.extra_tokens.requires_grad = requires_grad
-        if freeze_all or fd["freeze_embeddings_patch"]:
+        if (freeze_all or fd["freeze_embeddings_patch"]) and tr.embeddings.use_patch_embedding:
             set_grad(tr.embeddings.patch_embeddings, requires_grad)
         if (freeze_all or fd["freeze_embeddings_pos"]) and tr.embeddings.use_pos_embedding:
             set_grad(tr.embeddings.positional_embeddings, requires_grad)
@@ -444,6 +446,14 @@ class VTAMIQ(nn.Module):
                 pk = "transformer.embeddings.positional_embeddings.positional_embeddings"
                 names.append(pk)
                 sd[pk] = torch.zeros(1, self.spec.pos_grid ** 2 + 1, self.spec.hidden_size, device=device, dtype=torch.float32)
+            if not self.spec.use_patch_embedding:
+                # use_patch_embedding=False (transformer.py:473-480): no Conv2d; the engine's patch GEMM is never launched for pre-embedded input
+                # (vtq_forward_tokens), its weight slots just have to be filled
+                sp = self.spec
+                for pk, shape in (("transformer.embeddings.patch_embeddings.weight", (sp.hidden_size, 3, sp.patch_size, sp.patch_size)),
+                                  ("transformer.embeddings.patch_embeddings.bias", (sp.hidden_size,))):
+                    names.append(pk)
+                    sd[pk] = torch.zeros(*shape, device=device, dtype=torch.float32)
             keep = []
             descs = (_lib.VtqTensorDesc * len(names))()
             for i, k in enumerate(names):
@@ -494,11 +504,21 @@ class VTAMIQ(nn.Module):
         if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
             warnings.warn("vtamiq_amd.VTAMIQ.forward returns scores without an autograd graph (inference engine)")
             self._warned_grad = True
-        if patches_ref.dim() != 5 or patches_ref.shape != patches_dist.shape:
-            raise ValueError(f"patches must be two (B,N,3,P,P) tensors, got {tuple(patches_ref.shape)} / {tuple(patches_dist.shape)}")
-        B, N, Cc, P, P2 = patches_ref.shape
-        if (Cc, P, P2) != (3, self.spec.patch_size, self.spec.patch_size):
-            raise ValueError(f"patch shape {(Cc, P, P2)} != (3,{self.spec.patch_size},{self.spec.patch_size})")
+        # Embeddings.forward (transformer.py:527-535): a 5-D tensor goes through the patch convolution, anything else is taken as pre-embedded
+        # (B, N, H) rows -- whatever `use_patch_embedding` says; a model built without the convolution fails on 5-D input like the reference does
+        tokens_in = patches_ref.dim() != 5
+        if tokens_in:
+            if patches_ref.dim() != 3 or patches_ref.shape != patches_dist.shape or patches_ref.shape[2] != self.spec.hidden_size:
+                raise ValueError(f"pre-embedded input must be two (B,N,{self.spec.hidden_size}) tensors, got {tuple(patches_ref.shape)} / {tuple(patches_dist.shape)}")
+            B, N = patches_ref.shape[:2]
+        else:
+            if not self.spec.use_patch_embedding:
+                raise AttributeError("'Embeddings' object has no attribute 'patch_embeddings' (use_patch_embedding=False: pass pre-embedded (B,N,H) rows)")
+            if patches_ref.shape != patches_dist.shape:
+                raise ValueError(f"patches must be two (B,N,3,P,P) tensors, got {tuple(patches_ref.shape)} / {tuple(patches_dist.shape)}")
+            B, N, Cc, P, P2 = patches_ref.shape
+            if (Cc, P, P2) != (3, self.spec.patch_size, self.spec.patch_size):
+                raise ValueError(f"patch shape {(Cc, P, P2)} != (3,{self.spec.patch_size},{self.spec.patch_size})")
         if not self.spec.use_pos_embedding:
             # the reference never looks at `pos` then (transformer.py:539): whatever was passed, None included, has no effect.  The
             # engine's index kernel still wants coordinates: zeros (table row 1 of the all-zero table _ensure_engine installs)
@@ -523,7 +543,7 @@ class VTAMIQ(nn.Module):
                 if _trace is not None:
                     _lib.check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
                 try:
-                    _lib.check(lib.vtq_forward(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
+                    _lib.check((lib.vtq_forward_tokens if tokens_in else lib.vtq_forward)(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
                                                sr.data_ptr() if use_scales else None, sdist.data_ptr() if use_scales else None,
                                                B, N, q.data_ptr(), stream))
                 finally:

@@ -49,6 +49,7 @@ class ModelSpec:
     num_scales: int = 0           # scale embedding active iff num_scales > 1 (transformer.py:500)
     use_layer_scale: bool = False
     num_adapters: int = 0         # Adapter pairs per layer (transformer.py:177-194, 260-269); the forward uses pair 0 (backbone.py:54-57)
+    use_patch_embedding: bool = True # False: no patch Conv2d; the model is fed pre-embedded (B, N, H) rows (transformer.py:473-480, 534-535)
     use_pos_embedding: bool = True   # False: no UvPosEmbedding module, nothing added to the patches or to CLS (transformer.py:497-499, 514, 539)
     # VTAMIQ head
     calibrate: bool = True
@@ -130,8 +131,9 @@ class ModelSpec:
         out.append((e + "cls_token", (1, 1, H), "embed"))
         if self.num_extra_tokens > 0:
             out.append((e + "extra_tokens", (1, self.num_extra_tokens, H), "embed"))
-        out.append((e + "patch_embeddings.weight", (H, 3, P, P), "matrix"))
-        out.append((e + "patch_embeddings.bias", (H,), "bias"))
+        if self.use_patch_embedding:
+            out.append((e + "patch_embeddings.weight", (H, 3, P, P), "matrix"))
+            out.append((e + "patch_embeddings.bias", (H,), "bias"))
         if self.use_pos_embedding:
             out.append((e + "positional_embeddings.positional_embeddings", (1, self.pos_grid ** 2 + 1, H), "embed"))
         if self.use_scale_embedding:
@@ -201,8 +203,7 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
     cfg = get_vit_config(variant)
     if not vc.pop("use_cls_token", True):
         raise ValueError("use_cls_token=False is not runnable in the reference (transformer.py:485) and is rejected here")
-    if not vc.pop("use_patch_embedding", True):
-        raise NotImplementedError("use_patch_embedding=False (pre-embedded input) is outside the accelerated path")
+    use_patch = bool(vc.pop("use_patch_embedding", True))
     use_pos = bool(vc.pop("use_pos_embedding", True))
     num_adapters = int(vc.pop("num_adapters", 0))
     if num_adapters < 0:
@@ -224,7 +225,7 @@ def make_spec(vit_config: dict | None = None, *, calibrate=True, diff_scale=True
         variant=variant, hidden_size=cfg["hidden_size"], mlp_dim=cfg["mlp_dim"], num_heads=cfg["num_heads"],
         num_layers=num_layers, patch_size=cfg["patch_size"], pos_grid=cfg["img_dim"] // cfg["patch_size"],
         num_extra_tokens=int(vc.pop("num_extra_tokens", 0)), num_scales=int(vc.pop("num_scales", 0)),
-        use_layer_scale=bool(vc.pop("use_layer_scale", False)), num_adapters=num_adapters, use_pos_embedding=use_pos,
+        use_layer_scale=bool(vc.pop("use_layer_scale", False)), num_adapters=num_adapters, use_patch_embedding=use_patch, use_pos_embedding=use_pos,
         calibrate=bool(calibrate), diff_scale=bool(diff_scale), num_rgs=int(num_rgs), num_rcabs=int(num_rcabs),
         ca_reduction=int(ca_reduction))
     if vc:

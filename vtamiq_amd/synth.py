@@ -70,8 +70,12 @@ def make_inputs(spec: ModelSpec, B: int, N: int, seed: int = 1234, aligned: bool
     """
     P = spec.patch_size
     r = _rs(seed, f"inputs/{B}/{N}")
-    ref = r.uniform(-1.0, 1.0, size=(B, N, 3, P, P)).astype(np.float32)
-    dist = np.clip(ref + 0.1 * r.normal(size=ref.shape).astype(np.float32), -1.0, 1.0).astype(np.float32)
+    if getattr(spec, "use_patch_embedding", True):
+        ref = r.uniform(-1.0, 1.0, size=(B, N, 3, P, P)).astype(np.float32)
+        dist = np.clip(ref + 0.1 * r.normal(size=ref.shape).astype(np.float32), -1.0, 1.0).astype(np.float32)
+    else:           # a model without the patch convolution is fed pre-embedded rows: patches[B,2,N,H] (transformer.py:534-535)
+        ref = (0.3 * r.normal(size=(B, N, spec.hidden_size))).astype(np.float32)
+        dist = (ref + 0.03 * r.normal(size=ref.shape)).astype(np.float32)
     pos_ref = np.minimum(r.uniform(0.0, 1.0, size=(B, N, 2)), 1.0 - 1e-6).astype(np.float32)
     pos_ref = np.minimum(pos_ref, np.float32(1.0 - 1e-6))
     if aligned:
