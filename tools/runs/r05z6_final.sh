@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final tree of round 5: GPU suite (product library), the fp8 experiment's tests on its build, smoke, the default bench line
+# Final tree of round 5 (re-run after every later change of the session): GPU suite (product library), the fp8 experiment's tests on its build, smoke, the default bench line
 O=gpurun_out/r05z6; mkdir -p $O
 timeout 2400 python3 -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.txt
 VTQ_LIB_PATH=$PWD/vtamiq_amd/libvtamiq_hip_fp8.so timeout 1200 python3 -m pytest tests/test_gpu_fp8.py -m gpu -q 2>&1 | tail -2 > $O/pytest_gpu_fp8_build.txt
