@@ -31,8 +31,8 @@ PEAK_BF16_TFLOPS = 2516.6        # dense bf16 MFMA: 256 CU x 4096 flop/clk/CU x 
 # fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents (its cap is 2x the bf16 roofline)
 MFMA_PER_PRODUCT = {"bf16": 1.0, "bf16x3": 3.0, "fp16": 1.0, "fp16x2": 2.0, "fp16x3": 3.0, "fp8": 0.5}
 HEADLINE = "fp16x3"          # default `value` mode; OTHER_MODES are timed beside it
-OTHER_MODES = ("fp16x2", "fp16", "fp8")   # fp8: only when the loaded library is a build of the fp8 EXPERIMENT (python -m vtamiq_amd.build --fp8,
-                                          # VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so); the product library does not have the mode
+OTHER_MODES = ("fp16x2", "fp16", "fp8")   # fp8: the EXPERIMENT's own library (vtamiq_amd/libvtamiq_hip_fp8.so, built by __graft_entry__.build())
+                                          # through its own handle (_lib.load_fp8()); the product library does not have the mode
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -613,9 +613,9 @@ def main():
         return
 
     from vtamiq_amd import VTAMIQ, synth, _lib as _vlib
-    fp8_ok = bool(on_gpu and _vlib.has_fp8())
+    fp8_ok = bool(on_gpu and _vlib.fp8_available())
     if a.precision == "fp8" and not fp8_ok:
-        sys.exit("bench.py --precision fp8: the loaded library has no fp8 experiment (python -m vtamiq_amd.build --fp8; VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so)")
+        sys.exit("bench.py --precision fp8: vtamiq_amd/libvtamiq_hip_fp8.so (the fp8 experiment's library) is not built: python -m vtamiq_amd.build --fp8")
 
     def model_class(precision):
         if precision != "fp8":
@@ -717,7 +717,7 @@ def main():
         # what a default-constructed model runs: precision="auto" = this line's fp16x3 + the error word read after every forward
         "default_precision": "auto", "auto_overhead": (auto_cost or {}).get("overhead"), "auto_overhead_measured_in_this_run": auto_cost,
         "rank_devices": rank_devices,
-        "fp8_experiment_in_this_library": fp8_ok,
+        "fp8_experiment_library_loaded": fp8_ok,
         "rank_step_ms": {"min": min(headline_rank_times) / a.steps * 1e3, "max": max(headline_rank_times) / a.steps * 1e3},
         "allgather_us": allgather_us,
         "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: ViT-B/16 (L=12, T=1) FR pair forward, batch={B} pairs/GPU, "

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VTQ_ABI_VERSION 8
+#define VTQ_ABI_VERSION 9
 
 /* numerics mode of the dense contractions (fp32 accumulate, fp32 LayerNorm/softmax/residual in all of them).
  * bf16 and fp16 MFMAs run at the same rate on gfx950; fp16 carries 11 significand bits instead of 8 in the range the reference's
@@ -123,6 +123,11 @@ int  vtq_forward_tokens(vtq_handle h, const float* feats_ref, const float* feats
 int  vtq_forward_pairwise(vtq_handle h, const float* const* patches, const float* const* pos, const float* const* scales,
                           int32_t B, int32_t N, float* q_out, void* stream);
 
+/* vtq_forward_pairwise on PRE-EMBEDDED input (the (B, N, H) branch of Embeddings.forward, as vtq_forward_tokens): feats = HOST array of 3 DEVICE
+ * pointers {ref, dist1, dist2}, each (B, N, hidden_size) fp32 contiguous.  Bit-identical to two vtq_forward_tokens calls. */
+int  vtq_forward_pairwise_tokens(vtq_handle h, const float* const* feats, const float* const* pos, const float* const* scales,
+                                 int32_t B, int32_t N, float* q_out, void* stream);
+
 /* Input check.  The reference raises (IndexError / device assert) when a position lies outside [0, 1)
  * (transformer.py:417-421); vtq_forward clamps such an index into the table instead of gathering out of bounds and records it.
  * Bit 1: the CLS difference of some pair was not finite -- an operand left its format's range upstream (the fp16 operand modes
@@ -144,6 +149,14 @@ int  vtq_set_token_trace(vtq_handle h, float* buf);
  * 1 QKV, 2 attention, 3 out-proj, 4 LayerNorm 2, 5 fc1, 6 fc2; -1 = run everything; the scores of such a forward are
  * meaningless), and borrow the workspace: x = fp32 residual stream [rows, H], lnbuf = LayerNorm / attention output planes,
  * big = QKV / fc1 output planes, in the layouts DESIGN.md section 3 gives for the engine's precision. */
+/* Measurement hook for launches on CU-masked streams (hipExtStreamCreateWithCUMask; tools/cu_partition.py): size the persistent grids of
+ * the following launches for the CUs such a stream owns -- the 256x256 GEMM for `gemm_cus_per_xcd` workgroups on each of the 8 XCDs (its tile
+ * schedule is rebuilt for that grid), the pipelined attention kernel for `attention_cus` CUs.  0 = the whole device (the default).  Process-wide;
+ * results never depend on it. */
+int  vtq_debug_cu_partition(int32_t gemm_cus_per_xcd, int32_t attention_cus);
+/* Which CUs does a stream own?  Launches `nblocks` workgroups that hold a whole CU each (144 KiB of LDS) for ~spin_us microseconds;
+ * out[2 b] = XCC id, out[2 b + 1] = HW_ID register (SE / SH / CU fields) of workgroup b.  out: 2 * nblocks uint32 of device memory. */
+int  vtq_debug_cu_map(uint32_t* out, int32_t nblocks, int32_t spin_us, void* stream);
 int  vtq_debug_stop_after(vtq_handle h, int32_t stage);
 int  vtq_debug_buffers(vtq_handle h, void** x, void** lnbuf, void** big, int64_t* rows);
 /* Clock diagnostic of the GEMM kernel (MI355X_MICROARCH.md 'DVFS give-back' item 6).  Only a library built with -DVTQ_GEMM_DIAG

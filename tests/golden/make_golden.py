@@ -96,13 +96,13 @@ def seeded_state(spec, seed, stress_qk=None, stress_head=False):
     return stress_state(spec, seed, qk=float(stress_qk), head=stress_head)
 
 
-def load_seeded(model, spec, seed, stress_qk=None):
-    sd = {k: torch.from_numpy(v) for k, v in seeded_state(spec, seed, stress_qk).items()}
+def load_seeded(model, spec, seed, stress_qk=None, stress_head=False):
+    sd = {k: torch.from_numpy(v) for k, v in seeded_state(spec, seed, stress_qk, stress_head).items()}
     missing, unexpected = model.load_state_dict(sd, strict=True), None
     return sd
 
 
-def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False, stress_qk=None, token_num=None):
+def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False, stress_qk=None, token_num=None, stress_head=False):
     kw = json.loads(json.dumps(vtamiq_kwargs))
     spec = make_spec(**json.loads(json.dumps(kw)))
     if trace:
@@ -113,7 +113,7 @@ def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False,
     assert ref_keys == our_keys, (set(ref_keys) ^ set(our_keys))
     for k, shape, _ in spec.state_layout():
         assert tuple(model.state_dict()[k].shape) == tuple(shape), (k, shape)
-    load_seeded(model, spec, wseed, stress_qk)
+    load_seeded(model, spec, wseed, stress_qk, stress_head)
     patches, pos, scales = synth.make_inputs(spec, B, N, iseed, aligned=aligned)
     tp, tpos = torch.from_numpy(patches), torch.from_numpy(pos)
     p = (tp[:, 0].clone(), tp[:, 1].clone())
@@ -126,6 +126,8 @@ def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False,
     out = dict(kwargs=json.dumps(vtamiq_kwargs), B=B, N=N, wseed=wseed, iseed=iseed, aligned=int(aligned))
     if stress_qk is not None:
         out["stress_qk"] = np.float64(stress_qk)
+        if stress_head:
+            out["stress_head"] = np.int64(1)
     with torch.no_grad():
         q, aux = model(p, ps, sc)
         assert aux is None
@@ -144,14 +146,14 @@ def run_case(name, vtamiq_kwargs, B, N, wseed, iseed, aligned=True, trace=False,
         # the reference evaluated in float64 as well: on these weights two fp32 evaluations of the model differ by ~1e-4, so the
         # fp64 scores are what pins the restatement (oracle in fp64: 1e-13) and what the fp32 reference's own noise is measured against
         m64 = build_reference(kw).double()
-        m64.load_state_dict({k: torch.from_numpy(v).double() for k, v in seeded_state(spec, wseed, stress_qk).items()}, strict=True)
+        m64.load_state_dict({k: torch.from_numpy(v).double() for k, v in seeded_state(spec, wseed, stress_qk, stress_head).items()}, strict=True)
         with torch.no_grad():
             q64, _ = m64(tuple(t.double() for t in p), tuple(t.double() for t in ps), sc)
         out["q64"] = q64.numpy().astype(np.float64)
     # fingerprints of the regenerated tensors, to detect generator drift
     out["fp_patches"] = np.float64(patches.astype(np.float64).sum())
     out["fp_pos"] = np.float64(pos.astype(np.float64).sum())
-    sdnp = seeded_state(spec, wseed, stress_qk)
+    sdnp = seeded_state(spec, wseed, stress_qk, stress_head)
     out["fp_weights"] = np.float64(sum(float(v.astype(np.float64).sum()) for v in sdnp.values()))
     np.savez(os.path.join(HERE, f"{name}.npz"), **out)
     print(f"{name}: q={out['q']}")
@@ -397,6 +399,14 @@ def run_operating_point():
                     stress_head=True)
 
 
+def run_long():
+    """The long-sequence regime the reference advertises (README.md:85 "50, 500, and 5000 patches"; data/patch_sampling.py:450): ViT-B/16 L = 12 at
+    N = 5000 patches (S = 5001: attention is > 50 % of the flops) through the reference -- flat seeded weights (B = 2, fp32) and trained-like
+    statistics with the head at its operating point (B = 1, fp32 + float64); scores only (round 6; ~5 min of CPU, ~8 GB)."""
+    run_case("long_b2_n5000", dict(vit_config=dict(variant="ViT-B16")), B=2, N=5000, wseed=54, iseed=64)
+    run_case("long5h_b1_n5000", dict(vit_config=dict(variant="ViT-B16")), B=1, N=5000, wseed=55, iseed=65, stress_qk=5.0, stress_head=True)
+
+
 def run_stress():
     """The reference itself on weights with trained-ViT-like statistics (tests.helpers.stress_state: peaked softmax, outlier
     channels) -- the flat random init of the other cases exercises none of that (transformer.py:153-172)."""
@@ -442,6 +452,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--operating-point":   # only the operating-point ladder (added in round 5; ~10 min)
         run_operating_point()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--long":           # only the N = 5000 cases (added in round 6)
+        run_long()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--stress":         # only the trained-like-statistics cases (added in round 3)
         run_stress()

@@ -22,7 +22,8 @@ def load_case(name):
     kw = json.loads(str(g["kwargs"]))
     kw.setdefault("vit_config", {})["pretrained"] = False      # as make_golden.build_reference did for the reference: seeded weights follow
     spec = make_spec(**json.loads(json.dumps(kw)))
-    sd = stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"])) if "stress_qk" in g else synth.make_state_dict(spec, int(g["wseed"]))
+    sd = (stress_state(spec, int(g["wseed"]), qk=float(g["stress_qk"]), head=bool(int(g.get("stress_head", 0)))) if "stress_qk" in g
+          else synth.make_state_dict(spec, int(g["wseed"])))
     patches, pos, scales = synth.make_inputs(spec, int(g["B"]), int(g["N"]), int(g["iseed"]),
                                              aligned=bool(int(g.get("aligned", 1))))
     # generator drift guard: the fixtures were produced from exactly these tensors
@@ -34,6 +35,10 @@ def load_case(name):
 
 # the sizes bench.py runs, scored by the reference (scores only): BASELINE configs[1] and the reference-default topology row
 FULLSIZE_CASES = ["c2_b32_n500", "refdefault_b16_n512", "c4_vitl_b16_n1024"]     # the last: BASELINE configs[3] whole (ViT-L/16, 3 scales)
+
+# the long-sequence regime (reference README.md:85: "50, 500, and 5000 patches"): ViT-B/16 L = 12 at N = 5000, flat weights (B = 2) and trained-like
+# statistics through a head at its operating point (B = 1, fp32 + float64); make_golden.py --long
+LONG_CASES = ["long_b2_n5000", "long5h_b1_n5000"]
 
 LADDER_CASES = ["stress5_b64_n500"]       # 64 pairs at the BASELINE patch count on trained-like weights: scores only (fp32 + float64)
 # the same ladder through a head at a trained model's operating point (stress_state(head=True)): scores in [0.2, 0.8]

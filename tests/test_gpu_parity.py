@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, OPERATING_POINT_CASES, STRESS_CASES, gate_error, load_case, load_ladder_case, rel_err, split_inputs, stress_state
+from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, LONG_CASES, OPERATING_POINT_CASES, STRESS_CASES, gate_error, load_case, load_ladder_case, rel_err, split_inputs, stress_state
 from vtamiq_amd import VTAMIQ, _lib, synth
 from vtamiq_amd.predict import get_data_tuple, predict
 
@@ -84,7 +84,8 @@ def test_token_num_selects_the_iqa_token(precision, options):
 def test_pre_embedded_input():
     """Embeddings.forward's (B, N, H) branch (transformer.py:527-535): a model WITH the patch convolution handed 3-D rows skips it, like the reference
     (same weights otherwise: the oracle's scores); a model WITHOUT it handed 5-D patches fails on the missing module, like the reference; the pairwise
-    entry takes patches only."""
+    entry takes the same 3-D rows (vtq_forward_pairwise_tokens) and returns the bits of two plain calls; a negative `token_num` counts from the
+    last token like Python indexing into the reference's (B, H, T) rows (vtamiq.py:107-108)."""
     g, kw, spec, sd, (feats, pos, scales) = load_case("preemb_b3_n60")
     kw2 = json.loads(json.dumps(kw)); kw2["vit_config"].pop("use_patch_embedding")
     spec2 = VTAMIQ(**json.loads(json.dumps(kw2)), precision=MAIN).spec
@@ -100,8 +101,17 @@ def test_pre_embedded_input():
         assert torch.equal(nopatch(p, ps, sc)[0], q)        # the same engine path, the same bits
         with pytest.raises(AttributeError, match="patch_embeddings"):
             nopatch((torch.zeros(3, 60, 3, 16, 16, device=DEV),) * 2, ps, sc)
+        for m in (model, nopatch):
+            q1, q2 = m.forward_pairwise((p[0], p[1], p[1]), (ps[0], ps[1], ps[1]), (sc[0], sc[1], sc[1]))
+            assert torch.equal(q1, q) and torch.equal(q2, q)
         with pytest.raises(ValueError):
-            model.forward_pairwise((p[0], p[1], p[1]), (ps[0], ps[1], ps[1]), (sc[0], sc[1], sc[1]))
+            model.forward_pairwise((p[0], p[1], p[1][:, :-1]), (ps[0], ps[1], ps[1]), (sc[0], sc[1], sc[1]))
+        T = model.spec.num_tokens
+        model.token_num = -T                                 # == token 0
+        assert torch.equal(model(p, ps, sc)[0], q)
+        model.token_num = -T - 1
+        with pytest.raises(RuntimeError, match="vtq_set_iqa_token"):
+            model(p, ps, sc)
 
 
 def test_pos_is_not_looked_at_without_positional_embedding():
@@ -145,6 +155,44 @@ def test_golden_at_the_bench_sizes(name, precision):
             assert model.engine_precision == "fp16x3" and np.array_equal(q.view(np.uint32), q3.view(np.uint32))
     else:
         assert e["max_rel_rms"] < TOL[precision], e
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "auto", "bf16x3", "fp16x2", "fp16"])
+@pytest.mark.parametrize("name", LONG_CASES)
+def test_golden_long_sequence(name, precision):
+    """The long-sequence regime the reference advertises (README.md:85 "50, 500, and 5000 patches", data/patch_sampling.py:450): ViT-B/16 L = 12 at
+    N = 5000 (S = 5001 -- 20 query blocks of 256 rows and 79 key tiles per head; attention is > 50 % of the flops; the CLS tail's score
+    buffer is 5001 entries) against scores the REFERENCE produced (tests/golden/make_golden.py --long): flat seeded weights (2 pairs) and
+    trained-like statistics through a head at its operating point (1 pair; fp32 and float64 of the reference).  Parity mode: RAW relative
+    error of every score <= 1e-3, no floor.  The pruned CLS tail and the full last layer must agree, and the whole-batch scores must not
+    depend on the attention form."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    model = build(kw, sd, precision)
+    p, ps, sc = split_inputs(patches, pos, scales, device=DEV)
+    with torch.no_grad():
+        q = model(p, ps, sc)[0].cpu().numpy()
+    e = rel_err(q, g["q"])
+    e64 = rel_err(q, g["q64"]) if "q64" in g else None
+    print(f"\n[{name} {precision}] vs reference fp32 {e['max_rel']:.2e}" + (f", vs reference fp64 {e64['max_rel']:.2e}" if e64 else ""))
+    assert q.shape == (int(g["B"]),) and np.isfinite(q).all()
+    if precision in ("fp16x3", "auto"):
+        assert e["max_rel"] < TOL["fp16x3"], e
+        if e64:
+            assert e64["max_rel"] < TOL["fp16x3"], e64
+    else:
+        assert e["max_rel"] < {"bf16x3": 3e-3, "fp16x2": 5e-2, "fp16": 2.5e-1}[precision], e
+    if precision == "fp16x3":
+        with torch.no_grad():
+            q_full = build(kw, sd, precision, engine_options=_lib.OPT_FULL_LAST_LAYER)(p, ps, sc)[0].cpu().numpy()
+        assert rel_err(q_full, g["q"])["max_rel"] < TOL["fp16x3"] and rel_err(q_full, q)["max_rel"] < 2e-4
+        lib = _lib.load()
+        try:
+            _lib.check(lib.vtq_debug_attention_variant(0))            # the 4-wave kernel instead of the pipelined one: the same bits
+            with torch.no_grad():
+                q0 = build(kw, sd, precision)(p, ps, sc)[0].cpu().numpy()
+        finally:
+            _lib.check(lib.vtq_debug_attention_variant(-1))
+        assert np.array_equal(q0.view(np.uint32), q.view(np.uint32))
 
 
 @pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])

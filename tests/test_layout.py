@@ -5,6 +5,8 @@ import ctypes
 import json
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -61,9 +63,55 @@ def test_fp8_is_not_a_mode_of_the_product_model():
     assert not any(hasattr(VTAMIQ, n) for n in ("fp8_scales", "set_fp8_scales", "calibrate_fp8"))
     if os.path.basename(_lib.LIB_PATH) == "libvtamiq_hip.so":
         assert not _lib.has_fp8()
-        from vtamiq_amd.experimental_fp8 import VTAMIQFp8
-        with pytest.raises(RuntimeError, match="built without the fp8 experiment"):
-            VTAMIQFp8(vit_config=dict(variant="ViT-B16", num_keep_layers=1, pretrained=False))
+
+
+def test_fp8_experiment_loads_through_its_own_handle_in_a_fresh_interpreter():
+    """BASELINE configs[4]: `VTAMIQFp8(...)` constructs with NO environment variable -- the experiment's library is a second handle
+    (_lib.load_fp8()), the product library stays what `VTAMIQ` uses, and the two coexist in one process."""
+    from vtamiq_amd import build
+    build.build(verbose=False, fp8=True)
+    code = (
+        "from vtamiq_amd import VTAMIQ, _lib\n"
+        "from vtamiq_amd.experimental_fp8 import VTAMIQFp8\n"
+        "kw = dict(vit_config=dict(variant='ViT-B16', num_keep_layers=1, pretrained=False))\n"
+        "m8, m = VTAMIQFp8(**kw), VTAMIQ(**kw, precision='fp16x3')\n"
+        "a, b = m8._engine_lib(), m._engine_lib()\n"
+        "assert a is not b and _lib.has_fp8(a) and not _lib.has_fp8(b)\n"
+        "assert a._name.endswith('libvtamiq_hip_fp8.so') and b._name.endswith('libvtamiq_hip.so')\n"
+        "assert _lib.load() is b and _lib.load_fp8() is a and m8.precision == 'fp8'\n"
+        "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VTQ_")}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_vit_checkpoint_loads_into_a_model_without_patch_convolution():
+    """transformer.py:643-651 `load_from(weights, use_patch_embedding, use_pos_embedding)` skips the tensors of modules the model was built
+    without: a JAX ViT checkpoint must load into a pre-embedded-input model (and one without positional table) without 'unexpected keys'."""
+    import numpy as np
+    from vtamiq_amd import VTAMIQ, weights
+    H, L, G = 768, 1, 24
+    rs = np.random.RandomState(3)
+    w = {"cls": rs.randn(1, 1, H), "embedding/kernel": rs.randn(16, 16, 3, H), "embedding/bias": rs.randn(H),
+         "Transformer/posembed_input/pos_embedding": rs.randn(1, G * G + 1, H),
+         "Transformer/encoder_norm/scale": rs.randn(H), "Transformer/encoder_norm/bias": rs.randn(H)}
+    r = "Transformer/encoderblock_0"
+    for n in ("query", "key", "value"):
+        w[f"{r}/MultiHeadDotProductAttention_1/{n}/kernel"] = rs.randn(H, 12, 64)
+        w[f"{r}/MultiHeadDotProductAttention_1/{n}/bias"] = rs.randn(12, 64)
+    w[f"{r}/MultiHeadDotProductAttention_1/out/kernel"] = rs.randn(12, 64, H)
+    w[f"{r}/MultiHeadDotProductAttention_1/out/bias"] = rs.randn(H)
+    w[f"{r}/MlpBlock_3/Dense_0/kernel"], w[f"{r}/MlpBlock_3/Dense_0/bias"] = rs.randn(H, 4 * H), rs.randn(4 * H)
+    w[f"{r}/MlpBlock_3/Dense_1/kernel"], w[f"{r}/MlpBlock_3/Dense_1/bias"] = rs.randn(4 * H, H), rs.randn(H)
+    for n in ("LayerNorm_0", "LayerNorm_2"):
+        w[f"{r}/{n}/scale"], w[f"{r}/{n}/bias"] = rs.randn(H), rs.randn(H)
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    for extra in (dict(use_patch_embedding=False), dict(use_pos_embedding=False), dict(use_patch_embedding=False, use_pos_embedding=False), {}):
+        m = VTAMIQ(vit_config=dict(variant="ViT-B16", num_keep_layers=L, pretrained=False, **extra), precision="fp16x3")
+        weights.load_vit_npz(m, w)
+        sd = m.state_dict()
+        assert ("transformer.embeddings.patch_embeddings.weight" in sd) == extra.get("use_patch_embedding", True)
+        assert torch.equal(sd["transformer.encoder.encoder_norm.weight"], torch.from_numpy(w["Transformer/encoder_norm/scale"]))
 
 
 def test_config_struct_matches_header():

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vtamiq_oracle as O
-from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, OPERATING_POINT_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
+from tests.helpers import E2E_CASES, FULLSIZE_CASES, LADDER_CASES, LONG_CASES, OPERATING_POINT_CASES, STRESS_CASES, GOLDEN, gate_error, load_case, load_ladder_case, split_inputs, rel_err
 import os
 
 # fp32 op-order differences between the restatement and the reference modules stay below this
@@ -46,6 +46,21 @@ def test_e2e_q_at_the_bench_sizes(name):
     e = rel_err(q, g["q"][:n])
     tol = 1.5e-4 if name == "c2_b32_n500" else ORACLE_RTOL
     assert e["max_abs"] < tol * float(np.sqrt(np.mean(g["q"] ** 2))) and e["max_abs"] < 1e-6, e
+
+
+@pytest.mark.parametrize("name", LONG_CASES)
+def test_e2e_q_long_sequence(name):
+    """The long-sequence regime (reference README.md:85: 5000 patches; S = 5001, attention > 50 % of the flops): the oracle against the
+    reference's scores at ViT-B/16 L = 12, N = 5000 -- one pair here (~20 s of host work), the GPU test scores every pair.  The trained-like
+    case goes through a head at its operating point (score 0.45) and carries the reference's float64 score too: raw relative error."""
+    g, kw, spec, sd, (patches, pos, scales) = load_case(name)
+    p, ps, sc = split_inputs(patches[:1], pos[:1], None)
+    q = O.vtamiq_forward(O.to_torch(sd), spec, p, ps, sc)[0].numpy()
+    e = rel_err(q, g["q"][:1])
+    print(name, "oracle32-ref32", e["max_rel"], "" if "q64" not in g else ("oracle32-ref64", rel_err(q, g["q64"][:1])["max_rel"], "ref32-ref64", rel_err(g["q"][:1], g["q64"][:1])["max_rel"]))
+    assert e["max_rel"] < 1e-4, e
+    if "q64" in g:
+        assert rel_err(q, g["q64"][:1])["max_rel"] < 1e-4 and rel_err(g["q"], g["q64"])["max_rel"] < 1e-4
 
 
 @pytest.mark.parametrize("name", STRESS_CASES)

@@ -17,7 +17,7 @@ kw = dict(vit_config=dict(variant=a.variant, num_scales=a.scales, pretrained=Fal
 if a.refdefault:
     kw = dict(vit_config=dict(variant=a.variant, num_keep_layers=6, num_extra_tokens=8, use_layer_scale=True, num_scales=a.scales, pretrained=False), ca_reduction=16)
 from vtamiq_amd import _lib
-for prec in ("fp16x3", "fp16x2", "fp16", "bf16") + (("fp8",) if _lib.has_fp8() else ()):      # fp8: on a build of the experiment only
+for prec in ("fp16x3", "fp16x2", "fp16", "bf16") + (("fp8",) if _lib.fp8_available() else ()):      # fp8: the experiment's own library
     m = model_class(prec)(**json.loads(json.dumps(kw)), precision=prec)
     spec = m.spec
     sd = synth.make_state_dict(spec, 0)

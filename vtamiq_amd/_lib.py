@@ -7,6 +7,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTQ_LIB_PATH") or os.path.join(_HERE, "libvtamiq_hip.so")   # override: kernel A/B builds in tools/
+# the fp8 experiment's build of the same sources (python -m vtamiq_amd.build --fp8; include/vtamiq_hip_fp8.h).  It is a second library with its
+# own handle: load_fp8() -- nothing has to be exported before the import, and the product library stays the one every other path uses.
+LIB_PATH_FP8 = os.environ.get("VTQ_LIB_PATH_FP8") or os.path.join(_HERE, "libvtamiq_hip_fp8.so")
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -20,7 +23,7 @@ NUM = {"bf16": 1, "bf16x3": 3, "fp16": 17, "fp16x2": 18, "fp16x3": 19, "fp8": 33
 # MFMAs per product of the linear layers / of attention, per precision (bench.py)
 # (fp8: one e4m3 MFMA per product at twice the 16-bit rate = 0.5 bf16-MFMA-equivalents)
 MFMA_TERMS = {"bf16": (1, 1), "bf16x3": (3, 3), "fp16": (1, 1), "fp16x3": (3, 3), "fp16x2": (2, 3), "fp8": (0.5, 1)}
-ABI_VERSION = 8
+ABI_VERSION = 9
 OPT_FULL_LAST_LAYER = 1
 OPT_FP8_STATIC_SCALES = 2
 OPT_FUSED_LAYERNORM = 4
@@ -52,12 +55,16 @@ SIGNATURES = {
     "vtq_forward_tokens": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_forward_pairwise": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    "vtq_forward_pairwise_tokens": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_set_token_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtq_set_iqa_token": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vtq_debug_gemm_diag": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_attention_variant": (C.c_int, [C.c_int32]),
+    "vtq_debug_cu_partition": (C.c_int, [C.c_int32, C.c_int32]),
+    "vtq_debug_cu_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_attention_rule": (C.c_int, [C.c_int32] * 5),
     "vtq_debug_gemm_variant": (C.c_int, [C.c_int32]),
     "vtq_k_gemm_tile_rule": (C.c_int, [C.c_int32] * 4),
@@ -89,8 +96,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_void_p]),
 }
 
-# the fp8 experiment (include/vtamiq_hip_fp8.h): exported only by a library built with -DVTQ_WITH_FP8 (python -m vtamiq_amd.build --fp8,
-# selected with VTQ_LIB_PATH); bound when present
+# the fp8 experiment (include/vtamiq_hip_fp8.h): exported only by a library built with -DVTQ_WITH_FP8 (python -m vtamiq_amd.build --fp8 ->
+# LIB_PATH_FP8, load_fp8()); bound when present
 FP8_SIGNATURES = {
     "vtq_fp8_calibrate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vtq_fp8_get_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
@@ -102,22 +109,24 @@ FP8_SIGNATURES = {
     "vtq_fp8_reset": (C.c_int, [C.c_void_p]),
 }
 
-_lib = None
+_libs = {}            # absolute path -> bound CDLL: one handle per library file (RTLD_LOCAL: two builds of the same sources coexist)
 
 
-def load() -> C.CDLL:
-    """Load the engine library; RuntimeError (never a silent fallback) when it is absent or broken."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path: str | None = None) -> C.CDLL:
+    """Load (once per path) and bind an engine library -- the product library by default; RuntimeError (never a silent fallback) when it
+    is absent or broken."""
+    path = os.path.abspath(path or LIB_PATH)
+    lib = _libs.get(path)
+    if lib is not None:
+        return lib
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP engine is not built.  Run `python -m vtamiq_amd.build` "
+            f"{path} not found: the HIP engine is not built.  Run `python -m vtamiq_amd.build{' --fp8' if path == os.path.abspath(LIB_PATH_FP8) else ''}` "
             "(there is no CPU fallback on the product path).")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+        raise RuntimeError(f"failed to load {path}: {e}") from e
     # VTQ_LIB_PATH selects WHICH build is loaded (tools/build_abl.sh variants of this tree); it does not relax any check.  An A/B
     # build of an OLDER tree (different ABI: argument layouts may differ) loads only with VTQ_ALLOW_ABI_MISMATCH=1, with a warning.
     relaxed = os.environ.get("VTQ_ALLOW_ABI_MISMATCH") == "1"
@@ -134,20 +143,38 @@ def load() -> C.CDLL:
             fn.argtypes = args
     if lib.vtq_abi_version() != ABI_VERSION:
         if not relaxed:
-            raise RuntimeError(f"{LIB_PATH}: ABI version {lib.vtq_abi_version()}, this package binds version {ABI_VERSION} "
+            raise RuntimeError(f"{path}: ABI version {lib.vtq_abi_version()}, this package binds version {ABI_VERSION} "
                                "(rebuild: python -m vtamiq_amd.build)")
         import warnings
-        warnings.warn(f"{LIB_PATH}: ABI version {lib.vtq_abi_version()} != {ABI_VERSION} accepted (VTQ_ALLOW_ABI_MISMATCH=1): "
+        warnings.warn(f"{path}: ABI version {lib.vtq_abi_version()} != {ABI_VERSION} accepted (VTQ_ALLOW_ABI_MISMATCH=1): "
                       "struct / argument layouts may differ -- measurement use only")
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def has_fp8() -> bool:
-    """Is the loaded library a build of the fp8 experiment (-DVTQ_WITH_FP8)?  The product library is not."""
-    return hasattr(load(), "vtq_fp8_calibrate")
+def load_fp8() -> C.CDLL:
+    """The fp8 experiment's library (LIB_PATH_FP8) through its own handle; RuntimeError when it is not built or is not an fp8 build."""
+    lib = load(LIB_PATH_FP8)
+    if not has_fp8(lib):
+        raise RuntimeError(f"{LIB_PATH_FP8} was built without the fp8 experiment: `python -m vtamiq_amd.build --fp8 --force`")
+    return lib
 
 
-def check(rc: int) -> None:
+def has_fp8(lib: C.CDLL | None = None) -> bool:
+    """Is `lib` (default: the product library) a build of the fp8 experiment (-DVTQ_WITH_FP8)?  The product library is not."""
+    return hasattr(lib if lib is not None else load(), "vtq_fp8_calibrate")
+
+
+def fp8_available() -> bool:
+    """Does the fp8 experiment's library exist and load (tests: run or skip)?"""
+    try:
+        load_fp8()
+        return True
+    except RuntimeError:
+        return False
+
+
+def check(rc: int, lib: C.CDLL | None = None) -> None:
+    """Raise the library's error text for a non-zero status (`lib`: the handle the call went through; default the product library)."""
     if rc != 0:
-        raise RuntimeError("vtamiq_hip: " + load().vtq_last_error().decode(errors="replace"))
+        raise RuntimeError("vtamiq_hip: " + (lib if lib is not None else load()).vtq_last_error().decode(errors="replace"))

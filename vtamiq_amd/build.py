@@ -2,7 +2,7 @@
 
     python -m vtamiq_amd.build [--force]            the product library
     python -m vtamiq_amd.build --fp8 [--force]      libvtamiq_hip_fp8.so: the same sources with -DVTQ_WITH_FP8, i.e. with the fp8 experiment
-                                                    (include/vtamiq_hip_fp8.h, vtamiq_amd/experimental_fp8.py); select it with VTQ_LIB_PATH
+                                                    (include/vtamiq_hip_fp8.h, vtamiq_amd/experimental_fp8.py), loaded through its own handle (_lib.load_fp8())
 """
 from __future__ import annotations
 
@@ -59,7 +59,8 @@ def build(force: bool = False, verbose: bool = True, fp8: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # -Bsymbolic: every internal call binds inside this library (the product and the fp8 build share symbol names and coexist in a process)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -16,6 +16,7 @@
 //   * NSPLIT == 3: Q,K,V,P are hi/lo 16-bit pairs and each product is hi*hi + hi*lo + lo*hi (fp32 accumulate).
 //   * T = bf16 | f16 operand planes.  P (in (0, 1]) is split with a TRUNCATED hi part, so that lo = v - hi is exact in fp32:
 //     f16: v_cvt_pkrtz for a pair (subnormal results are kept: tools/micro/split_probe.hip); bf16: mask + subtract.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -1156,7 +1157,10 @@ hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int6
 static int g_attn_variant = -1;                 // -1: the rule below (or VTQ_ATTN_VARIANT), 0: 4-wave kernel, 1: pipelined kernel
 void attention_set_variant(int v) { g_attn_variant = v; }
 
-static int device_cus(int* cus) {
+static std::atomic<int> g_attn_cus{0};          // measurement hook (a launch on a CU-masked stream): 0 = the device's CU count
+void attention_set_cus(int cus) { g_attn_cus.store(cus, std::memory_order_relaxed); }
+
+int device_cus(int* cus) {
     static std::mutex mu;
     static int cached[64] = {0};
     int dev = 0;
@@ -1214,6 +1218,7 @@ hipError_t launch_attention(const void* qkv, int64_t plane, void* out, int64_t o
     if (q_log2 && num.terms != 3) return hipErrorInvalidValue;
     int cus = 0;
     if (device_cus(&cus) || cus < 1) return hipErrorInvalidDevice;
+    if (const int o = g_attn_cus.load(std::memory_order_relaxed); o > 0) cus = o;
     const int v = pick_variant(nseq, S_pad, H, num.terms, cus);
     if (!num.f16) {
         if (num.terms == 1) return launch_attention_v<bf16, 1>(v, qkv, plane, out, o_plane, nseq, S, S_pad, H, s, out8_scale, obs, cus, q_log2);

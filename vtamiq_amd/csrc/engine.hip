@@ -871,6 +871,19 @@ int vtq_debug_gemm_variant(int32_t v) {
     return 0;
 }
 
+int vtq_debug_cu_partition(int32_t gemm_cus_per_xcd, int32_t attention_cus) {
+    if (gemm_cus_per_xcd < 0 || gemm_cus_per_xcd > 32 || attention_cus < 0 || attention_cus > 4096) return fail("vtq_debug_cu_partition: %d, %d", (int)gemm_cus_per_xcd, (int)attention_cus);
+    gemm_set_cus_per_xcd(gemm_cus_per_xcd);
+    attention_set_cus(attention_cus);
+    return 0;
+}
+
+int vtq_debug_cu_map(uint32_t* out, int32_t nblocks, int32_t spin_us, void* stream) {
+    if (!out || nblocks < 1 || nblocks > 4096 || spin_us < 0 || spin_us > 100000) return fail("vtq_debug_cu_map: bad argument");
+    HIP_TRY(launch_cu_map(out, nblocks, spin_us, (hipStream_t)stream));
+    return 0;
+}
+
 int vtq_k_gemm_tile_rule(int32_t M, int32_t N, int32_t K, int32_t num) {
     const Num nm = num_from_code(num);
     if (!num_valid(nm)) return -1;
@@ -1083,6 +1096,13 @@ int vtq_forward_pairwise(vtq_handle e, const float* const* patches, const float*
     if (!patches || !pos) return fail("vtq_forward_pairwise: null argument");
     const float* sc[3] = {scales ? scales[0] : nullptr, scales ? scales[1] : nullptr, scales ? scales[2] : nullptr};
     return forward_impl(e, 3, patches, pos, sc, B, N, q_out, stream);
+}
+
+int vtq_forward_pairwise_tokens(vtq_handle e, const float* const* feats, const float* const* pos, const float* const* scales, int32_t B,
+                                int32_t N, float* q_out, void* stream) {
+    if (!feats || !pos) return fail("vtq_forward_pairwise_tokens: null argument");
+    const float* sc[3] = {scales ? scales[0] : nullptr, scales ? scales[1] : nullptr, scales ? scales[2] : nullptr};
+    return forward_impl(e, 3, feats, pos, sc, B, N, q_out, stream, true);
 }
 
 int vtq_input_errors(vtq_handle e, int32_t* flags, void* stream) {

@@ -37,6 +37,7 @@
 //     32 tiles it works on at a time are (32/cg row panels) x (cg column tiles) with the cg W tiles L2-resident; the run
 //     ends with 128-row half tiles so the last round is filled in half-tile granules.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -905,9 +906,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 constexpr int kXcds = 8, kCusPerXcd = 32, kNumCus = kXcds * kCusPerXcd;
 constexpr double kHalfCost = 0.57;
 
+// Workgroups per XCD of the persistent launch: all 32 CUs, unless a measurement narrows the grid -- vtq_debug_gemm_cus (a launch on a
+// CU-masked stream, tools/cu_partition.py: the grid must match the CUs the stream owns, the schedule is rebuilt for it) or, in
+// -DVTQ_MEASURE builds, VTQ_GEMM_CUS.  Results never depend on it (the tile -> workgroup assignment does not enter the arithmetic).
+std::atomic<int> g_cus_per_xcd{0};
 int cus_per_xcd() {
-    static const int n = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_CUS"); const int k = v ? atoi(v) : kCusPerXcd; return (k >= 1 && k <= kCusPerXcd) ? k : kCusPerXcd; }();
-    return n;                                    // measurement knob: workgroups per XCD of the persistent launch (default: all 32 CUs)
+    static const int env = [] { const char* v = VTQ_MEASURE_ENV("VTQ_GEMM_CUS"); const int k = v ? atoi(v) : kCusPerXcd; return (k >= 1 && k <= kCusPerXcd) ? k : kCusPerXcd; }();
+    const int g = g_cus_per_xcd.load(std::memory_order_relaxed);
+    return (g >= 1 && g <= kCusPerXcd) ? g : env;
 }
 
 double greedy_makespan(int n_full, int n_half) {
@@ -1021,13 +1027,13 @@ int column_group(int ntn, int K, int wpl) {
 struct DevSched { int* dev; int nwg; };
 hipError_t schedule_for(int ntm, int ntn, int cg, bool dynamic, DevSched& ds, hipStream_t s) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, DevSched> cache;
+    static std::map<std::tuple<int, int, int, int, int, int>, DevSched> cache;
     static std::vector<std::vector<int>*> staged;              // host images of uploads in flight on some stream: kept for the process lifetime
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(dev, ntm, ntn, cg, (int)dynamic);
+    const auto key = std::make_tuple(dev, ntm, ntn, cg, (int)dynamic, cus_per_xcd());
     auto it = cache.find(key);
     if (it != cache.end()) { ds = it->second; return hipSuccess; }
     // First use of a shape on this device.  The engine does this from vtq_reserve / the top of vtq_forward (gemm_prepare), never
@@ -1129,27 +1135,32 @@ std::vector<int> gemm_tile_schedule(int ntm, int ntn, int K, int wpl) {
     return build_schedule(ntm, ntn, column_group(ntn, K, wpl));
 }
 
-namespace { int g_tile_variant = GEMM_TILE_AUTO; }
-void gemm_set_variant(int v) { g_tile_variant = v; }
+namespace { std::atomic<int> g_tile_variant{GEMM_TILE_AUTO}; }
+void gemm_set_variant(int v) { g_tile_variant.store(v, std::memory_order_relaxed); }
+void gemm_set_cus_per_xcd(int n) { g_cus_per_xcd.store(n, std::memory_order_relaxed); }
 
 // Which tile shape serves an (M, N, K) launch (profiles/r05_gemm_tile_shapes.txt, fp16x3 on the encoder's four GEMMs at the row counts of
 // B = 1 .. 32 pairs).  The persistent 256x256 kernel wins from 64 of its tiles up (it is MFMA-bound per tile, the small tiles are bound by
 // a CU's L1 -> LDS fill rate: 4x the operand bytes per flop at 64x64); below that most CUs would idle, and one workgroup per small tile
 // is faster: 64x64 tiles while they fit one or two co-resident workgroups per CU, 128x128 beyond.  Pure speed choice (bitwise contract
 // of gemm_st.hip); fp8 operands have the 256x256 kernel only.
-int gemm_tile_rule(int M, int N, int K, Num num) {
+int gemm_tile_rule(int M, int N, int K, Num num, int cus) {
+    if (cus < 1) cus = kNumCus;
     if (num.f16 == 2 || M <= 0 || M % 256 || N <= 0 || N % 256 || K % 64) return GEMM_TILE_256;
     const int t256 = (M / 256) * (N / 256);
     if (t256 >= 64) return GEMM_TILE_256;
     const int n64 = 16 * t256;
-    if (n64 <= kNumCus) return GEMM_ST_64;                 // one workgroup per CU, ring of 3
-    if (n64 <= 2 * kNumCus) return GEMM_ST_64X2;           // two co-resident workgroups per CU, ring of 2
+    if (n64 <= cus) return GEMM_ST_64;                     // one workgroup per CU, ring of 3
+    if (n64 <= 2 * cus) return GEMM_ST_64X2;               // two co-resident workgroups per CU, ring of 2
     return GEMM_ST_128;
 }
 
 hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s) {
     if (num_valid(num) && num.f16 != 2) {
-        const int v = g_tile_variant != GEMM_TILE_AUTO ? g_tile_variant : gemm_tile_rule(a.M, a.N, a.K, num);
+        const int forced = g_tile_variant.load(std::memory_order_relaxed);
+        int cus = 0;
+        if (forced == GEMM_TILE_AUTO && device_cus(&cus)) return hipErrorInvalidDevice;      // the CU count of the CURRENT device (a partitioned part has fewer)
+        const int v = forced != GEMM_TILE_AUTO ? forced : gemm_tile_rule(a.M, a.N, a.K, num, cus);
         if (v != GEMM_TILE_256) return launch_gemm_st(a, num, epilogue, v, s);
     }
     const int bk2 = (num.f16 == 2) ? 256 : ((num.terms == 1) ? 128 : 64);     // two K tiles: the DMA ring's buffer parity is fixed across tiles

@@ -114,8 +114,11 @@ hipError_t launch_gemm(const GemmArgs& a, Num num, int epilogue, hipStream_t s);
 // depend on it.  GEMM_TILE_256: the persistent 256x256 / 128x256 kernel of gemm.hip; GEMM_ST_*: one workgroup per small tile (gemm_st.hip).
 enum { GEMM_TILE_AUTO = -1, GEMM_TILE_256 = 0, GEMM_ST_64 = 1, GEMM_ST_64X2 = 2, GEMM_ST_128 = 3 };
 hipError_t launch_gemm_st(const GemmArgs& a, Num num, int epilogue, int variant, hipStream_t s);
-int gemm_tile_rule(int M, int N, int K, Num num);     // host only: the shape launch_gemm would pick
+int gemm_tile_rule(int M, int N, int K, Num num, int cus = 0);     // host only: the shape launch_gemm would pick on a device of `cus` CUs (0: 256)
 void gemm_set_variant(int v);                        // test / measurement hook: GEMM_TILE_AUTO (default) or a forced shape
+void gemm_set_cus_per_xcd(int n);                    // measurement hook: workgroups per XCD of the persistent 256x256 launch (0 = all 32)
+hipError_t launch_cu_map(unsigned* out, int nblocks, int spin_us, hipStream_t s);   // measurement: (XCC id, HW_ID) of each workgroup, one per CU
+int device_cus(int* cus);                            // CU count of the current device (cached per device); non-zero on failure
 // Whole-row residual GEMM with LayerNorm in its epilogue (gemm_rowln.hip): x[M, 768] += gamma * (A W^T + bias), then (ln_w != NULL)
 // out planes = LayerNorm(x; ln_w, ln_b).  N = 768, 3-term operand formats, M % 128 == 0, K % 32 == 0.
 struct RowLnArgs {
@@ -131,6 +134,7 @@ hipError_t launch_gemm_rowln(const RowLnArgs& a, Num num, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
 int attention_rule(int nseq, int S_pad, int H, int terms, int cus);    // host-only: the form launch_attention picks: 0 four-wave kernel, 1 pipelined kernel, 2 split
 void attention_set_variant(int v);               // test / measurement hook: -1 the rule, 0 / 1 / 2 as above
+void attention_set_cus(int cus);                 // measurement hook: size the persistent attention grid for `cus` CUs (0 = the device's)
 unsigned long long* gemm_diag_buffer();         // the buffer of gemm_set_diag (attention's diagnostic build shares it)
 void gemm_set_diag(unsigned long long* buf, int shadow);
 bool gemm_is_diag_build();

@@ -8,6 +8,7 @@
 // with such operands before a single byte has moved; bench.py prints it beside the nominal peak (roofline.practical_peak_tflops_measured_here).
 // Measurement only: nothing on the forward path calls it.
 #include <chrono>
+#include <mutex>
 
 #include "dev_common.h"
 #include "kernels.h"
@@ -58,7 +59,34 @@ __global__ __launch_bounds__(512) void mfma_stream_kernel(float* out, int iters,
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// Where do the workgroups of a launch land?  One workgroup per CU (144 KiB of LDS), each records XCC id and HW_ID (SE / SH / CU fields) and
+// stays for ~spin_us so that all of them are resident together.  tools/cu_partition.py reads it back to check what a CU-masked stream owns.
+__global__ __launch_bounds__(256) void cu_map_kernel(unsigned* out, long long spin_ticks) {
+    extern __shared__ char lds_hold[];
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        lds_hold[0] = (char)xcc;
+        out[2 * blockIdx.x] = xcc;
+        out[2 * blockIdx.x + 1] = hw;
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+}
+
 }  // namespace
+
+hipError_t launch_cu_map(unsigned* out, int nblocks, int spin_us, hipStream_t s) {
+    constexpr int LDS = 144 * 1024;
+    static std::once_flag once;
+    static hipError_t attr = hipSuccess;
+    std::call_once(once, [] { attr = hipFuncSetAttribute((const void*)cu_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(cu_map_kernel, dim3(nblocks), dim3(256), LDS, s, out, (long long)spin_us * 100);      // wall_clock64: 100 MHz
+    return hipGetLastError();
+}
 
 // -> tflops: MFMA-issue TFLOP/s of the stream over >= timed_s seconds after >= warm_s seconds of the same load; ghz: the clock that rate
 // implies (2 waves per SIMD, 16 cycles per MFMA)

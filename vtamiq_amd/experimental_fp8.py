@@ -1,11 +1,10 @@
 """The fp8 EXPERIMENT (BASELINE.json configs[4]) -- not part of the product path.
 
 `VTAMIQFp8` is `vtamiq_amd.VTAMIQ` plus the e4m3 mode: linear layers on OCP e4m3 operands with the MX-scaled MFMA (2x the bf16 MFMA rate),
-weights with per-output-channel power-of-two scales, activations with per-tensor scales calibrated on the first batch.  It needs a library
-built with the experiment (include/vtamiq_hip_fp8.h):
-
-    python -m vtamiq_amd.build --fp8
-    VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so python ...
+weights with per-output-channel power-of-two scales, activations with per-tensor scales calibrated on the first batch.  It lives in its own build of the
+engine sources (include/vtamiq_hip_fp8.h; `python -m vtamiq_amd.build --fp8` -> vtamiq_amd/libvtamiq_hip_fp8.so, which `__graft_entry__.build()`
+makes next to the product library) and reaches it through its own ctypes handle (`_lib.load_fp8()`): no environment variable, and the
+product library is still the one every other model in the process uses.
 
 Why it is here and not in `VTAMIQ`: it is a THROUGHPUT experiment, not a scoring mode -- 3 mantissa bits of activation
 precision put its scores tens of percent from the fp32 model's on random-init weights and SROCC 0.66 - 0.84 from them on a distortion ladder
@@ -32,13 +31,14 @@ class VTAMIQFp8(VTAMIQ):
     _FP8_EXPERIMENT = True
 
     def __init__(self, *args, precision: str = "fp8", **kwargs):
-        if not _lib.has_fp8():
-            raise RuntimeError(f"{_lib.LIB_PATH} was built without the fp8 experiment: `python -m vtamiq_amd.build --fp8` and "
-                               "VTQ_LIB_PATH=vtamiq_amd/libvtamiq_hip_fp8.so")
+        _lib.load_fp8()                                   # RuntimeError when the experiment's library is not built
         super().__init__(*args, precision=precision, **kwargs)
         if self.precision == "fp8" and self.spec.num_adapters > 0:
             raise NotImplementedError("adapters are not available in the fp8 mode (the adapter input would need an e4m3 copy of the "
                                       "branch output); use a 16-bit precision")
+
+    def _engine_lib(self):
+        return _lib.load_fp8()
 
     # ---- state that follows the engine's lifetime -------------------------------------------------------------------------------
     def _weights_loaded(self, reload_: bool):
@@ -51,7 +51,7 @@ class VTAMIQFp8(VTAMIQ):
         # auto-calibrated scales fitted the weights the engine held before: forget them on both sides, the next forward calibrates
         d["_fp8_saved"] = None
         d["_fp8_checked"] = 0
-        _lib.check(_lib.load().vtq_fp8_reset(self._engine))
+        self._check(self._engine_lib().vtq_fp8_reset(self._engine))
 
     def _launch_checked(self, device, launch):
         if self.engine_precision != "fp8":
@@ -80,7 +80,7 @@ class VTAMIQFp8(VTAMIQ):
         repeats that on a batch of your choice, set_fp8_scales() installs given ones."""
         if self._engine is None or self.engine_precision != "fp8":
             raise RuntimeError("fp8_scales: no fp8 engine yet (run a forward first)")
-        lib = _lib.load()
+        lib = self._engine_lib()
         n = lib.vtq_fp8_get_scales(self._engine, None, 0)
         buf = (C.c_float * n)()
         lib.vtq_fp8_get_scales(self._engine, buf, n)
@@ -97,7 +97,7 @@ class VTAMIQFp8(VTAMIQ):
         for i in range(L):
             flat += [sc["ln1"][i], sc["att"][i], sc["ln2"][i], sc["gelu"][i]]
         buf = (C.c_float * len(flat))(*flat)
-        _lib.check(_lib.load().vtq_fp8_set_scales(self._engine, buf, len(flat)))
+        self._check(self._engine_lib().vtq_fp8_set_scales(self._engine, buf, len(flat)))
 
     def set_fp8_scales(self, sc):
         """Install activation scales (the dict fp8_scales() returns, e.g. from a checkpoint's side file or from rank 0:
@@ -123,7 +123,7 @@ class VTAMIQFp8(VTAMIQ):
             B, N = patches[0].shape[:2]
             q = torch.empty(B, device=device, dtype=torch.float32)
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.vtq_fp8_calibrate(self._engine, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+            self._check(lib.vtq_fp8_calibrate(self._engine, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
                                              sc[0].data_ptr() if use_scales else None, sc[1].data_ptr() if use_scales else None,
                                              B, N, q.data_ptr(), stream))
         self.__dict__["_fp8_checked"] = 0

@@ -258,6 +258,13 @@ class VTAMIQ(nn.Module):
             set_grad(self.q_predictor, requires_grad)
 
     # ---- engine management --------------------------------------------------------------------------------
+    def _engine_lib(self):
+        """The C-ABI library this model's engine lives in: the product library (the fp8 experiment's subclass returns its own build)."""
+        return _lib.load()
+
+    def _check(self, rc: int) -> None:
+        _lib.check(rc, self._engine_lib())
+
     def _walk(self):
         """The model's own tree as (module, name, parameter) and (parent, name, child) triples -- what _signature re-checks by identity
         on every forward.  No process-global torch hook is involved: other modules in the process cost nothing and
@@ -307,10 +314,10 @@ class VTAMIQ(nn.Module):
             if park:
                 parked[self.__dict__.get("_engine_precision")] = (eng, self.__dict__.get("_weights_sig"))
             else:
-                _lib.load().vtq_destroy(eng)
+                self._engine_lib().vtq_destroy(eng)
         if not park:
             for h, _ in parked.values():
-                _lib.load().vtq_destroy(h)
+                self._engine_lib().vtq_destroy(h)
             parked.clear()
         self.__dict__["_engine"] = None
         self.__dict__["_weights_sig"] = None
@@ -342,7 +349,7 @@ class VTAMIQ(nn.Module):
         flags = C.c_int32(0)
         with torch.cuda.device(self._engine_device):
             stream = torch.cuda.current_stream(self._engine_device).cuda_stream
-            _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
+            self._check(self._engine_lib().vtq_input_errors(self._engine, C.byref(flags), stream))
         flags.value |= self.__dict__.pop("_flags_seen", 0)       # bits an earlier look of a subclass already collected (and cleared)
         if flags.value & 1:
             raise IndexError("pos outside [0, 1): index out of range in the positional-embedding table (transformer.py:417-421)")
@@ -365,7 +372,7 @@ class VTAMIQ(nn.Module):
         flags = C.c_int32(0)
         with torch.cuda.device(self._engine_device):
             stream = torch.cuda.current_stream(self._engine_device).cuda_stream
-            _lib.check(_lib.load().vtq_input_errors(self._engine, C.byref(flags), stream))
+            self._check(self._engine_lib().vtq_input_errors(self._engine, C.byref(flags), stream))
         return flags.value
 
     def _enqueue(self, device, launch):
@@ -373,7 +380,9 @@ class VTAMIQ(nn.Module):
         lib = self._ensure_engine(device)
         # vtamiq.py:57, 107-108: `token_num` picks the token row the head consumes ("can be CLS token or extra_token"); the reference
         # reads the attribute at every forward, so does this (a value outside the model's tokens is refused by the library)
-        _lib.check(lib.vtq_set_iqa_token(self._engine, int(self.token_num)))
+        # (Python indexing into the (B, H, T) token rows: a negative index counts from the last register token)
+        t = int(self.token_num)
+        self._check(lib.vtq_set_iqa_token(self._engine, t + self.spec.num_tokens if t < 0 else t))
         launch(lib)
 
     def _launch_checked(self, device, launch):
@@ -397,6 +406,11 @@ class VTAMIQ(nn.Module):
                     self._enqueue(device, launch)            # the scores handed back are the parity mode's (the healthy pairs' bits included)
                     flags2 = (flags2 & 1) | (self._read_flags() & 1)
                 else:
+                    # the switch is sticky: the parked fp16x3 engine (packed weights + workspace) will not be used again
+                    for h, _ in self.__dict__.get("_parked", {}).values():
+                        lib_ = self._engine_lib()
+                        lib_.vtq_destroy(h)
+                    self.__dict__.get("_parked", {}).clear()
                     warnings.warn(f"[VTAMIQ] an activation or weight left the fp16 operand range (|v| > 65504) in precision "
                                   f"{AUTO_FIRST!r}: this model now runs {AUTO_FALLBACK!r} (fp32 operand range, the same 3-MFMA "
                                   "split; the call was repeated)")
@@ -409,7 +423,7 @@ class VTAMIQ(nn.Module):
             self.check_inputs()
 
     def _ensure_engine(self, device: torch.device):
-        lib = _lib.load()
+        lib = self._engine_lib()
         if self._engine is not None and self._engine_device != device:
             self._release_engine()
         elif self._engine is not None and self._engine_precision != self.engine_precision:
@@ -429,7 +443,7 @@ class VTAMIQ(nn.Module):
                 ca_hidden=s.ca_hidden, precision=_PRECISIONS[self.engine_precision], num_adapters=s.num_adapters,
                 options=self.engine_options)
             h = C.c_void_p()
-            _lib.check(lib.vtq_create(C.byref(cfg), C.byref(h)))
+            self._check(lib.vtq_create(C.byref(cfg), C.byref(h)))
             self._engine, self._engine_device, self._engine_precision = h, device, self.engine_precision
             self._weights_sig = None
             self._engine_created()
@@ -464,7 +478,7 @@ class VTAMIQ(nn.Module):
                 descs[i] = _lib.VtqTensorDesc(k.encode(), t.data_ptr(), t.numel())
             stream = torch.cuda.current_stream(device).cuda_stream
             reload_ = self._weights_sig is not None
-            _lib.check(lib.vtq_load_weights(self._engine, descs, len(names), stream))
+            self._check(lib.vtq_load_weights(self._engine, descs, len(names), stream))
             self._weights_sig = sig
             self._weights_loaded(reload_)
         return lib
@@ -541,9 +555,9 @@ class VTAMIQ(nn.Module):
 
             def launch(lib):
                 if _trace is not None:
-                    _lib.check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
+                    self._check(lib.vtq_set_token_trace(self._engine, _trace.data_ptr()))
                 try:
-                    _lib.check((lib.vtq_forward_tokens if tokens_in else lib.vtq_forward)(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
+                    self._check((lib.vtq_forward_tokens if tokens_in else lib.vtq_forward)(self._engine, pr.data_ptr(), pd.data_ptr(), qr.data_ptr(), qd.data_ptr(),
                                                sr.data_ptr() if use_scales else None, sdist.data_ptr() if use_scales else None,
                                                B, N, q.data_ptr(), stream))
                 finally:
@@ -565,8 +579,15 @@ class VTAMIQ(nn.Module):
             raise RuntimeError("VTAMIQ (vtamiq_amd) runs on an MI355X only: move the model and inputs to 'cuda'. "
                                "There is no CPU fallback on the product path.")
         B, N = patches[0].shape[:2]
+        # Embeddings.forward (transformer.py:527-535), as in forward(): 5-D tensors go through the patch convolution, 3-D ones are pre-embedded rows
+        tokens_in = patches[0].dim() != 5
         for t in patches:
-            if tuple(t.shape) != (B, N, 3, self.spec.patch_size, self.spec.patch_size):
+            if tokens_in:
+                if tuple(t.shape) != (B, N, self.spec.hidden_size):
+                    raise ValueError(f"pre-embedded input must be three (B,N,{self.spec.hidden_size}) tensors, got {tuple(t.shape)}")
+            elif not self.spec.use_patch_embedding:
+                raise AttributeError("'Embeddings' object has no attribute 'patch_embeddings' (use_patch_embedding=False: pass pre-embedded (B,N,H) rows)")
+            elif tuple(t.shape) != (B, N, 3, self.spec.patch_size, self.spec.patch_size):
                 raise ValueError(f"patches must be three (B,N,3,P,P) tensors, got {tuple(t.shape)}")
         if not self.spec.use_pos_embedding:            # as in forward(): `pos` is not looked at
             pos = (torch.zeros(B, N, 2, device=device, dtype=torch.float32),) * 3
@@ -583,7 +604,7 @@ class VTAMIQ(nn.Module):
             q = torch.empty(2 * B, device=device, dtype=torch.float32)
             arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
             stream = torch.cuda.current_stream(device).cuda_stream
-            self._launch_checked(device, lambda lib: _lib.check(lib.vtq_forward_pairwise(
+            self._launch_checked(device, lambda lib: self._check((lib.vtq_forward_pairwise_tokens if tokens_in else lib.vtq_forward_pairwise)(
                 self._engine, arr(pt), arr(ps), arr(sc) if use_scales else None, B, N, q.data_ptr(), stream)))
         return q[:B], q[B:]
 
@@ -592,14 +613,14 @@ class VTAMIQ(nn.Module):
         mask = 0
         for c in classes:
             mask |= 1 << _lib.KERNEL_CLASSES.index(c)
-        _lib.check(_lib.load().vtq_profile_enable(self._engine, mask))
+        self._check(self._engine_lib().vtq_profile_enable(self._engine, mask))
 
     def profile_collect(self):
         n = len(_lib.KERNEL_CLASSES)
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()
-        _lib.check(_lib.load().vtq_profile_collect(self._engine, ms, cnt))
+        self._check(self._engine_lib().vtq_profile_collect(self._engine, ms, cnt))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(_lib.KERNEL_CLASSES)}
 
     def workspace_bytes(self, B, N):
-        return int(_lib.load().vtq_workspace_bytes(self._engine, B, N)) if self._engine is not None else 0
+        return int(self._engine_lib().vtq_workspace_bytes(self._engine, B, N)) if self._engine is not None else 0

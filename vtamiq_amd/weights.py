@@ -97,6 +97,9 @@ def load_vit_npz(model, npz) -> None:
     sd = convert_vit_npz(weights, spec.hidden_size, spec.num_layers, spec.pos_grid ** 2 + 1)
     if not spec.use_pos_embedding:                      # transformer.py:656-657: the table is read only into a model that has one
         sd.pop("transformer.embeddings.positional_embeddings.positional_embeddings")
+    if not spec.use_patch_embedding:                    # transformer.py:643-651: the conv weights are read only into a model that has the conv
+        sd.pop("transformer.embeddings.patch_embeddings.weight")
+        sd.pop("transformer.embeddings.patch_embeddings.bias")
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if unexpected:
         raise RuntimeError(f"unexpected keys from the ViT checkpoint: {unexpected[:4]}")
