@@ -149,6 +149,10 @@ int  vtq_set_token_trace(vtq_handle h, float* buf);
  * 1 QKV, 2 attention, 3 out-proj, 4 LayerNorm 2, 5 fc1, 6 fc2; -1 = run everything; the scores of such a forward are
  * meaningless), and borrow the workspace: x = fp32 residual stream [rows, H], lnbuf = LayerNorm / attention output planes,
  * big = QKV / fc1 output planes, in the layouts DESIGN.md section 3 gives for the engine's precision. */
+/* Measurement hook: how the pipelined attention kernel's persistent workgroups walk the (sequence, head, 256-row block) items -- 0 (default) XCD-strided:
+ * the workgroups of an XCD take the blocks of the same few (sequence, head) pairs side by side, so a pair's K / V tiles are fetched once per XCD;
+ * 1: the round-3 walk (consecutive blocks per workgroup; paired when a pair has two blocks).  Same results either way. */
+int  vtq_debug_attention_map(int32_t m);
 /* Measurement hook for launches on CU-masked streams (hipExtStreamCreateWithCUMask; tools/cu_partition.py): size the persistent grids of
  * the following launches for the CUs such a stream owns -- the 256x256 GEMM for `gemm_cus_per_xcd` workgroups on each of the 8 XCDs (its tile
  * schedule is rebuilt for that grid), the pipelined attention kernel for `attention_cus` CUs.  0 = the whole device (the default).  Process-wide;

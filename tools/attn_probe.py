@@ -65,6 +65,12 @@ for fmt in a.fmt:
         line += (f"  [pipelined] in-kernel clock {ghz:.3f} GHz; {waves:.0f} waves, lifetime {d[0].item() / waves:.0f} cyc = {d[1].item() / waves / 100:.1f} us, "
                  f"{tiles / waves:.0f} tiles each; per wave and tile: phase 1 (QK^T || split) {per(2):.0f} | phase 2 (PV || softmax) {per(3):.0f} | seam / copies {per(4):.0f} | "
                  f"wait + barrier {per(5):.0f} cyc (lifetime/tiles {d[0].item() / tiles:.0f}); prologue {d[9].item() / waves:.0f} cyc per wave")
+        nk = dw[:, 13].long()
+        n0, n1, n2 = (nk & 0xFFFFF).sum().item(), ((nk >> 20) & 0xFFFFF).sum().item(), ((nk >> 40) & 0xFFFFF).sum().item()
+        if n0 + n1 + n2 > 0:
+            line += (f"\n    whole iterations by kind (cycles per wave): plain {d[10].item() / max(n0, 1):.0f} (x{n0 / waves:.1f} per wave) | writing the previous block's output "
+                     f"{d[11].item() / max(n1, 1):.0f} (x{n1 / waves:.1f}; write_block itself {d[14].item() / max(n1, 1):.0f}) | loading the next block's Q {d[12].item() / max(n2, 1):.0f} (x{n2 / waves:.1f}); "
+                     f"after the last iteration (final output) {d[15].item() / waves:.0f}")
         for grp in (0, 1):
             sel = dw.view(-1, 8, 16)[:, 4 * grp:4 * grp + 4].reshape(-1, 16).sum(dim=0)
             t = sel[7].item()

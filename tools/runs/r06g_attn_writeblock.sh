@@ -1,0 +1,21 @@
+#!/bin/bash
+# Pipelined attention kernel: the finished block's output formed and split once (fp16: split4_f16) -- tests, then shipped vs wbold (two split2 passes;
+# otherwise the same tree: XCD-strided walk, Q prefetch, early write) vs seam0 (round-5 seam handling), one box, interleaved; stamps of the shipped form
+cd "$(dirname "$0")/../.."
+o=gpurun_out/r06g; mkdir -p $o
+timeout 900 python3 -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "attention" 2>&1 | tail -3 | tee $o/pytest_attention.txt
+for r in 1 2 3; do
+  for v in shipped wbold seam0; do
+    if [ $v = shipped ]; then unset VTQ_LIB_PATH; else export VTQ_LIB_PATH=tools/_abl/$v.so; fi
+    timeout 200 python3 tools/attn_probe.py --variant 1 --fmt fp16x3 --tag $v 2>&1 | grep -v amdgpu | tee -a $o/sustained.txt
+  done
+done
+for r in 1 2 3; do
+  for v in shipped wbold seam0; do
+    if [ $v = shipped ]; then unset VTQ_LIB_PATH; else export VTQ_LIB_PATH=tools/_abl/$v.so; fi
+    echo "## $v (round $r)" | tee -a $o/classes.txt
+    timeout 300 python3 tools/class_profile.py --precision fp16x3 --steps 20 2>&1 | grep -E "ms/step unprofiled|attention" | tee -a $o/classes.txt
+  done
+done
+unset VTQ_LIB_PATH
+VTQ_LIB_PATH=tools/_abl/adiag.so timeout 200 python3 tools/attn_probe.py --variant 1 --fmt fp16x3 --tag adiag 2>&1 | grep -v amdgpu | tee -a $o/stamps.txt

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vtq_debug_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vtq_debug_gemm_diag": (C.c_int, [C.c_void_p, C.c_int32]),
     "vtq_debug_attention_variant": (C.c_int, [C.c_int32]),
+    "vtq_debug_attention_map": (C.c_int, [C.c_int32]),
     "vtq_debug_cu_partition": (C.c_int, [C.c_int32, C.c_int32]),
     "vtq_debug_cu_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vtq_k_attention_rule": (C.c_int, [C.c_int32] * 5),

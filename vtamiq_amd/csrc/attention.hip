@@ -457,6 +457,12 @@ struct PPFrags {                      // DIST + 1 rolling fragment buffers: grou
 #ifndef VTQ_SW_NOFILL
 #define VTQ_SW_NOFILL 0
 #endif
+#ifndef VTQ_SW_QPF
+#define VTQ_SW_QPF 1                  // the next block's Q rows are pulled into L2 two iterations before they are loaded (0: measurement builds)
+#endif
+#ifndef VTQ_SW_EARLY_WRITE
+#define VTQ_SW_EARLY_WRITE 1          // a finished block's output is written at the top of the next iteration (0: in its middle, the round-3 place)
+#endif
 #ifndef VTQ_SW_PRIO
 #define VTQ_SW_PRIO 0                 // measurement builds: issue priority alternating between the two waves of a SIMD (1: per phase, 2: per fragment group, 3: static for waves 4-7)
 #endif
@@ -554,11 +560,25 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     const int nqb = (Sq + 255) / 256, nh = H / 64;
     const int nt = (S + KT - 1) / KT;
     const int ld = 3 * H;
-    // Blocks of this workgroup: b0, b0 + bstep, ... < b1.  With two query blocks per (sequence, head) and a grid that divides evenly,
-    // workgroups w and w + 8 (same XCD under the round-robin dispatch) take the two query blocks of the same pairs at the same time, so
-    // that the second reader of every K / V tile finds it in that XCD's L2; otherwise contiguous runs of blocks.
+    // Blocks of this workgroup: b0, b0 + bstep, ... < b1.
+    // per == 0 (the default): XCD-STRIDED.  XCD x (= blockIdx & 7 under the round-robin dispatch; a speed assumption only) owns a contiguous run of
+    // (sequence, head) items, and its workgroups walk that run together: slot sl takes blocks r0 + sl, r0 + sl + n, ... (n = workgroups of the
+    // XCD).  At any time the CUs of an XCD therefore work on the SAME few (sequence, head) pairs -- all nqb query blocks of a pair run side by
+    // side and in step -- so every K / V tile comes from HBM once and from that XCD's L2 for the other readers, whatever nqb is (S = 501: the
+    // two blocks of a pair, as the paired form before; S = 1025: four; S = 5001: twenty -- a pair's K / V there are 2.5 MB, which one CU walking
+    // its blocks one after the other re-read from the Infinity Cache nqb times).
+    // per > 0 (measurement: vtq_debug_attention_map(1)): the round-3 form -- `per` consecutive blocks per workgroup, or, with two query blocks per
+    // pair and an evenly divided grid, workgroups w and w + 8 on the two blocks of the same pairs.
     int b0, b1, bstep;
-    if (VTQ_SW_PAIRED && nqb == 2 && (gridDim.x & 15) == 0 && (int)gridDim.x * per == nblk) {
+    if (per == 0) {
+        const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+        const int nx = ((int)gridDim.x - x + 7) >> 3;
+        const int items = nblk / nqb;
+        const int i0 = (int)((long long)items * x >> 3), i1 = (int)((long long)items * (x + 1) >> 3);
+        b0 = i0 * nqb + sl;
+        bstep = nx;
+        b1 = i1 * nqb;
+    } else if (VTQ_SW_PAIRED && nqb == 2 && (gridDim.x & 15) == 0 && (int)gridDim.x * per == nblk) {
         const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
         const int g = x * ((int)gridDim.x >> 4) + (sl >> 1);
         b0 = 2 * g * per + (sl & 1);
@@ -580,6 +600,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     const float sc = 0.125f * 1.4426950408889634f;
 #ifdef VTQ_ATTN_DIAG
     unsigned long long dg_k0, dg_r0, dg_t, dg_p1 = 0, dg_p2 = 0, dg_bar = 0, dg_pro = 0, dg_rest = 0;
+    unsigned long long dg_it0 = 0, dg_kind[3] = {0, 0, 0}, dg_nkind[3] = {0, 0, 0}, dg_wb = 0, dg_tail0 = 0;   // whole iterations by kind: plain / writes a block / loads Q
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_k0), "=s"(dg_r0) :: "memory");
     dg_t = dg_k0;
 #endif
@@ -674,6 +695,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    uint32_t q_pf = 0;                           // destination of the Q prefetch (never read; reserved while a prefetch may be in flight)
     uint32_t lw_keep[2] = {0, 0};                // lo words of a half step, carried to the group that has room for them (split_half)
     float m_run = -1e30f, l_run = 0.f, l_fin = 0.f;
     float amax8 = 0.f;
@@ -711,18 +733,32 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             }
         } else {
             const int r_row = lane >> 3, r_chunk = lane & 7;      // read-back: 8 lanes per row, 4 x 8 rows
+            // O / l is formed and split ONCE: the hi halves go to the LDS image, the lo halves wait in 16 registers for the second plane.  (Formed per
+            // plane with split2, as up to round 5, the block cost 5 200 cycles per wave, most of it the 450 vector instructions of two passes --
+            // all 8 waves at once, nothing to overlap with; fp16: the 6-instruction split of four values, bit-identical to split2.)
+            tx4 lo_keep[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                         // chunk k = 4 d + g4 of row c, bytes 8 hh .. 8 hh + 7
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = o_acc[k >> 2][4 * (k & 3) + e] * inv;
+                tx4 hv;
+                if constexpr (NSPLIT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float u = v4[e]; asm volatile("" : "+v"(u)); hv[e] = (T)u; }   // rounded product, then converted
+                } else if constexpr (std::is_same<T, f16>::value) {
+                    split4_f16(v4, hv, lo_keep[k]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { T x, y; split2<T>(v4[e], x, y); hv[e] = x; lo_keep[k][e] = y; }
+                }
+                *(tx4*)(o_stage + c * 128 + ((k ^ (c & 7)) << 4) + 8 * hh) = hv;
+            }
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
+                if (pl == 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {                     // chunk k = 4 d + g4 of row c, bytes 8 hh .. 8 hh + 7
-                    tx4 pv;                                       // formed per plane (the split is cheap; 32 registers of planes are not)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = o_acc[k >> 2][4 * (k & 3) + e] * inv;
-                        if constexpr (NSPLIT == 1) { float u = v; asm volatile("" : "+v"(u)); pv[e] = (T)u; }   // rounded product, then converted
-                        else { T x, y; split2<T>(v, x, y); pv[e] = pl == 0 ? x : y; }
-                    }
-                    *(tx4*)(o_stage + c * 128 + ((k ^ (c & 7)) << 4) + 8 * hh) = pv;
+                    for (int k = 0; k < 8; ++k) *(tx4*)(o_stage + c * 128 + ((k ^ (c & 7)) << 4) + 8 * hh) = lo_keep[k];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -957,7 +993,20 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
 #if VTQ_SW_PRIO == 1 || VTQ_SW_PRIO == 3
         prio(1);                                   // phase 1: waves 4 - 7 favoured (1); phase 2: waves 0 - 3 (below)
 #endif
-        if (rescale && !wr_pending) {              // a pending block's O is written and cleared below (its successor starts from zero)
+        // Output of the block that ended with the previous iteration's PV.  Written HERE, at the top: phase 1 does not touch O, the stores are
+        // older than this iteration's LDS-DMA and have both phases as cover before the counted wait at the end (all CUs reach their seams
+        // together: 16 MB of stores in one burst, which one phase did not cover).
+        const bool had_pending = wr_pending;       // the successor block starts from zero: nothing to rescale
+#ifdef VTQ_ATTN_DIAG
+        dg_it0 = dg_t;
+#endif
+#if VTQ_SW_EARLY_WRITE
+        if (wr_pending) { write_block(l_fin, wr_b, wr_qb); wr_pending = false; }
+#endif
+#ifdef VTQ_ATTN_DIAG
+        if (had_pending) { VTQ_AT_SPAN(dg_wb); }
+#endif
+        if (rescale && !had_pending) {
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -996,9 +1045,9 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             static_for<8, 8 + DIST>([&](auto gc) __attribute__((always_inline)) { issue_g(gc, kaddr, vaddr); });
         }
         VTQ_AT_SPAN(dg_p1);
-        // output of the block that ended with the previous iteration's PV: phase 1 did not touch O; its stores are older than this
-        // iteration's LDS-DMA and have phase 2 as cover before the counted wait at the end
+#if !VTQ_SW_EARLY_WRITE
         if (wr_pending) { write_block(l_fin, wr_b, wr_qb); wr_pending = false; }
+#endif
         // at a seam the finished block's row sums are set aside and the statistics restart before the next tile's softmax
         const bool seam = (ct + 1 == nt);
         if (seam) { l_fin = l_run; m_run = -1e30f; l_run = 0.f; }
@@ -1052,8 +1101,27 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             const int bq = (tb_next == 0 ? cb + bstep : cb) + bstep;
             if (tb_next == nt - 1 && bq < b1 && !VTQ_SW_NOQ) { load_q_async(bq, qf); q_loaded = true; }
         }
-        sent = issue_tile();                                    // tile tau + 3: younger than the Q loads and stores, so vmcnt(NI) below covers them
+        sent = issue_tile();                    // tile tau + 3: younger than the Q loads and stores, so vmcnt(NI) below covers them
         if (active1 || active2) phase2();
+        // L2 prefetch of the Q rows that will be loaded two iterations from now: one dword per 128-byte row segment (lane = row, half-wave =
+        // plane), into a register nothing reads.  All CUs reach their seams together, so the Q loads of a seam are a 16 MB burst that HBM
+        // serves in ~3.5 us -- longer than the phase that covers them; pulled into L2 ahead of time they return at L2 latency.  Issued
+        // AFTER this iteration's LDS-DMA, behind phase 2 (younger: this iteration's counted wait leaves it in flight, the next one's covers it).
+        bool q_pf_sent = false;
+#if VTQ_SW_QPF
+        if constexpr (more) {
+            const int bq = (tb_next == 0 ? cb + bstep : cb) + bstep;
+            if (tb_next == nt - 3 && bq < b1) {
+                int qb;
+                const int64_t base = block_base(bq, qb);
+                int qr = qb * 256 + wave * 32 + c;
+                qr = qr < Sq ? qr : Sq - 1;
+                const T* ptr = qkv + (NPL == 2 ? hh : 0) * plane + base + (int64_t)qr * ld;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(q_pf) : "v"(ptr) : "memory");
+                q_pf_sent = true;
+            }
+        }
+#endif
         if constexpr (more) finish_softmax(); else rescale = false;
         VTQ_AT_SPAN(dg_p2);
         if (seam) {
@@ -1066,8 +1134,10 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
 #pragma unroll
         for (int d = 0; d < 2; ++d) sA[d] = sB[d];
         VTQ_AT_SPAN(dg_rest);
-        if (sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI) : "memory");
+        if (sent && q_pf_sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI + 1) : "memory");
+        else if (sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(q_pf));                         // the prefetch's destination stays reserved (it may still be in flight)
         // everything older than tile tau + 3 has landed: tile tau + 2 (its V is read two iterations from now) gets its masked rows zeroed
 #ifndef VTQ_ATTN_NO_VMASK
         if (tau + 2 < NT && ib2 == nt - 1) zero_masked_v(tau + 2);
@@ -1077,9 +1147,15 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if constexpr (NSPLIT == 3) { if (q_loaded && !q_log2) prescale_q<T>(qf, sc); }
         pp_barrier();
         VTQ_AT_SPAN(dg_bar);
+#ifdef VTQ_ATTN_DIAG
+        { const int kd = had_pending ? 1 : (q_loaded ? 2 : 0); dg_kind[kd] += dg_t - dg_it0; dg_nkind[kd] += 1; }
+#endif
     };
     for (int tau = 0; tau < NT - 1; ++tau) iteration(std::true_type{}, tau);
     iteration(std::false_type{}, NT - 1);
+#ifdef VTQ_ATTN_DIAG
+    dg_tail0 = dg_t;
+#endif
     write_block(l_fin, wr_b, wr_qb);             // the last block of the list
     if (out8_scale > 0.f) fp8_report(obs, amax8, out8_scale);
 #ifdef VTQ_ATTN_DIAG
@@ -1090,6 +1166,7 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
             unsigned long long* dq = diag + ((size_t)blockIdx.x * 8 + wave) * 16;
             dq[0] = dg_k1 - dg_k0; dq[1] = dg_r1 - dg_r0; dq[2] = dg_p1; dq[3] = dg_p2; dq[4] = dg_rest; dq[5] = dg_bar; dq[6] = 1; dq[7] = NT; dq[8] = 0;
             dq[9] = dg_pro;
+            dq[10] = dg_kind[0]; dq[11] = dg_kind[1]; dq[12] = dg_kind[2]; dq[13] = dg_nkind[0] | (dg_nkind[1] << 20) | (dg_nkind[2] << 40); dq[14] = dg_wb; dq[15] = dg_k1 - dg_tail0;
         }
     }
 #endif
@@ -1126,6 +1203,9 @@ hipError_t launch_attention_t(const void* qkv, int64_t plane, void* out, int64_t
     return hipGetLastError();
 }
 
+static std::atomic<int> g_attn_map{0};          // measurement hook: 0 = XCD-strided block walk (default), 1 = the round-3 contiguous / paired walk
+void attention_set_map(int m) { g_attn_map.store(m, std::memory_order_relaxed); }
+
 // Pipelined kernel: persistent grid of at most one workgroup per CU (160 KB of LDS in the 3-term formats), `per` consecutive blocks each.
 template <typename T, int NSPLIT>
 hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int64_t o_plane, int nseq, int S, int S_pad, int H, hipStream_t s,
@@ -1147,8 +1227,19 @@ hipError_t launch_attention_sw_t(const void* qkv, int64_t plane, void* out, int6
         }
     }
     const int nblk = ((Sq + 255) / 256) * (H / 64) * nseq;
-    const int per = (nblk + cus - 1) / cus;
-    const dim3 grid((nblk + per - 1) / per), blk(512);
+    int per = (nblk + cus - 1) / cus;
+    dim3 grid((nblk + per - 1) / per), blk(512);
+    if (g_attn_map.load(std::memory_order_relaxed) != 1 && cus >= 8 && nblk >= 8) {
+        // XCD-strided walk (see the kernel): a grid that is a multiple of 8, at most one workgroup per CU; the rounds of the busiest XCD are
+        // ceil(its blocks / its workgroups), so fewer workgroups than CUs are used when that does not add a round (fewer half-empty last rounds)
+        const int nqb = (Sq + 255) / 256, items = nblk / nqb;
+        const int xmax = ((items + 7) / 8) * nqb;                      // blocks of the busiest XCD
+        int nx = cus / 8 < xmax ? cus / 8 : xmax;
+        const int rounds = (xmax + nx - 1) / nx;
+        nx = (xmax + rounds - 1) / rounds;
+        grid = dim3(8 * nx);
+        per = 0;
+    }
     hipLaunchKernelGGL((attention_sw_kernel<T, NSPLIT>), grid, blk, LDS, s, (const T*)qkv, plane, (T*)out, o_plane, S, S_pad, H, nblk, per, out8_scale, obs,
                        gemm_diag_buffer(), q_log2 ? 1 : 0, Sq);
     return hipGetLastError();

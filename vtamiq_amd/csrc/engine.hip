@@ -878,6 +878,12 @@ int vtq_debug_cu_partition(int32_t gemm_cus_per_xcd, int32_t attention_cus) {
     return 0;
 }
 
+int vtq_debug_attention_map(int32_t m) {
+    if (m < 0 || m > 1) return fail("vtq_debug_attention_map: %d", (int)m);
+    attention_set_map(m);
+    return 0;
+}
+
 int vtq_debug_cu_map(uint32_t* out, int32_t nblocks, int32_t spin_us, void* stream) {
     if (!out || nblocks < 1 || nblocks > 4096 || spin_us < 0 || spin_us > 100000) return fail("vtq_debug_cu_map: bad argument");
     HIP_TRY(launch_cu_map(out, nblocks, spin_us, (hipStream_t)stream));

@@ -41,6 +41,7 @@ inline bool num_valid(Num n) {
 //   VTQ_ATTN_DIAG         attention.hip: per-wave phase stamps (profiles/r03_attention_anatomy.txt)
 //   VTQ_ATTN_NO_VMASK     attention.hip: without the zeroing of masked keys' V rows (profiles/r04_attention_vmask_ab.txt)
 //   VTQ_SW_NOFILL / NOMFMA / NOSTORE / NOQ / NODMA / PAIRED / DIST / HALFREADS   attention.hip pipelined kernel: skeleton ablations, read-ahead distance
+//   VTQ_SW_QPF=0 / VTQ_SW_EARLY_WRITE=0   attention.hip pipelined kernel: without the L2 prefetch of the next block's Q / with the finished block's output written mid-iteration (profiles/r06_attention_loop.txt)
 //   VTQ_SW_PRIO=1|2|3     attention.hip: s_setprio alternating between the two waves of a SIMD per phase / per fragment group / static for waves 4-7 (profiles/r05_attention_prio.txt)
 //   VTQ_SW_SEAM_STAGGER=n attention.hip: every second workgroup of an XCD starts n us late (profiles/r05_attention_seams.txt)
 //   VTQ_LIBM_ERF          dev_common.h: erff() instead of the fitted exact-erf GELU (accuracy cross-check)
@@ -134,6 +135,7 @@ hipError_t launch_gemm_rowln(const RowLnArgs& a, Num num, hipStream_t s);
 // diagnostic builds: stamp buffer (256 workgroups x 8 words, device memory, or NULL) and shadow-VALU count of the following launches
 int attention_rule(int nseq, int S_pad, int H, int terms, int cus);    // host-only: the form launch_attention picks: 0 four-wave kernel, 1 pipelined kernel, 2 split
 void attention_set_variant(int v);               // test / measurement hook: -1 the rule, 0 / 1 / 2 as above
+void attention_set_map(int m);                   // measurement hook: block walk of the pipelined kernel, 0 = XCD-strided (default), 1 = contiguous / paired (round 3)
 void attention_set_cus(int cus);                 // measurement hook: size the persistent attention grid for `cus` CUs (0 = the device's)
 unsigned long long* gemm_diag_buffer();         // the buffer of gemm_set_diag (attention's diagnostic build shares it)
 void gemm_set_diag(unsigned long long* buf, int shadow);
