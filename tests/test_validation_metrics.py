@@ -56,6 +56,12 @@ def test_hip_metrics_match_reference_vectors(name):
         got = validate.compute_correlations_cat_flat(dev[0], dev[1], reps)
     for f in FIELDS:
         assert abs(got[f] - float(G[f"{name}_{f}"])) <= TOL[f], (f, got[f], float(G[f"{name}_{f}"]))
+    # the deferred form (fit on a worker thread, nothing waits for the device until result()): the same numbers, bit for bit
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pend = validate.compute_correlations_cat_flat(dev[0], dev[1], reps, defer=True)
+        later = pend.result()
+    assert all((later[f] == got[f]) or (np.isnan(later[f]) and np.isnan(got[f])) for f in FIELDS) and pend.done()
     if reps > 1:                                             # bit-exact: same summation order as numpy's axis-0 reduction
         m = validate.average_over_repeats(torch.from_numpy(G[name + "_pred"]).cuda(), reps).cpu().numpy()
         assert np.array_equal(m, G[name + "_mean"])
@@ -99,3 +105,6 @@ def test_predict_repeats_equals_separate_passes():
     assert torch.allclose(mean, qp.double().reshape(R, B).mean(0), rtol=0, atol=1e-15)
     step, corr = validate.do_validation(m, None, torch.device("cuda"), False, [tuple(t.cpu() for t in d) for d in datas[:1]], num_repeats=2)
     assert step == 2 and set(corr) == {"SROCC", "KROCC", "PLCC", "RMSE", "PLCC_NOFIT", "RMSE_NOFIT"}
+    step2, pend = validate.do_validation(m, None, torch.device("cuda"), False, [tuple(t.cpu() for t in d) for d in datas[:1]], num_repeats=2, defer=True)
+    later = pend.result()
+    assert step2 == 2 and all((later[k] == corr[k]) or (np.isnan(later[k]) and np.isnan(corr[k])) for k in corr)

@@ -54,9 +54,9 @@ def _fit_function1(p, x):
     return p[0] * (0.5 - 1.0 / (1.0 + np.exp(p[1] * (x - p[2]) + CORRELATIONS_EPS))) + abs(p[3]) * x + p[4]
 
 
-def compute_correlations(a: torch.Tensor, b: torch.Tensor, normalize: bool = True) -> dict:
-    """a (targets), b (predictions): device vectors.  Same six fields as utils/misc/correlations.py:21-52."""
-    import scipy.optimize
+def _enqueue_rank_metrics(a: torch.Tensor, b: torch.Tensor, normalize: bool):
+    """Device part: ranks / Kendall pair counts / Pearson / RMSE kernels and ONE device -> host copy into pinned memory, all enqueued on the
+    current stream; -> (pinned host vector, n, event recorded behind the copy).  Nothing here waits for the GPU."""
     _need_cuda(a, "compute_correlations")
     _need_cuda(b, "compute_correlations")
     a = a.detach().reshape(-1).double().contiguous()
@@ -69,7 +69,17 @@ def compute_correlations(a: torch.Tensor, b: torch.Tensor, normalize: bool = Tru
     out = torch.empty(3, dtype=torch.float64, device=a.device)
     _lib.check(_lib.load().vtq_k_rank_metrics(a.data_ptr(), b.data_ptr(), n, int(bool(normalize)), work.data_ptr(),
                                               counts.data_ptr(), out.data_ptr(), _stream()))
-    host = torch.cat([out, counts.double(), work[:2 * n]]).cpu().numpy()          # the loop's one device -> host copy
+    dev = torch.cat([out, counts.double(), work[:2 * n]])
+    host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+    host.copy_(dev, non_blocking=True)                                # the loop's one device -> host copy
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, n, ev, (a, b, work, dev)                             # the device tensors stay referenced until the copy has run
+
+
+def _finish_correlations(host: np.ndarray, n: int) -> dict:
+    """Host part: Kendall's tau-b from the exact pair counts, the logistic fit (scipy.optimize.leastsq, as the reference), PLCC / RMSE."""
+    import scipy.optimize
     spearman, pearson_nofit, rmse_nofit = float(host[0]), float(host[1]), float(host[2])
     con_minus_dis, xtie, ytie = (int(round(v)) // 2 for v in host[3:6])
     aa, bb = host[6:6 + n], host[6 + n:6 + 2 * n]
@@ -95,13 +105,52 @@ def compute_correlations(a: torch.Tensor, b: torch.Tensor, normalize: bool = Tru
             PLCC_NOFIT_FIELD: pearson_nofit, RMSE_NOFIT_FIELD: rmse_nofit}
 
 
-def compute_correlations_cat_flat(ys, yp, num_repeats: int = 1) -> dict:
-    """ys, yp: lists of per-batch device tensors in loop order (train.py:403-409)."""
+def compute_correlations(a: torch.Tensor, b: torch.Tensor, normalize: bool = True) -> dict:
+    """a (targets), b (predictions): device vectors.  Same six fields as utils/misc/correlations.py:21-52."""
+    host, n, ev, keep = _enqueue_rank_metrics(a, b, normalize)
+    ev.synchronize()
+    return _finish_correlations(host.numpy(), n)
+
+
+class PendingCorrelations:
+    """The correlations of a validation set whose host part (the logistic fit: ~1 000 residual evaluations by MINPACK, 30 - 40 ms for 1 280
+    scores) runs on a worker thread: the caller goes on enqueueing the NEXT pass (train.py runs a validation and a test pass per epoch,
+    train.py:583-644) and asks for `result()` when it needs the numbers.  The device part was enqueued by the constructor's caller; the
+    worker waits for ITS event, never for the device."""
+    _pool = None
+
+    def __init__(self, host, n, ev, keep):
+        import concurrent.futures
+        if PendingCorrelations._pool is None:
+            PendingCorrelations._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="vtq-fit")
+        self._keep = keep
+
+        def work():
+            ev.synchronize()
+            return _finish_correlations(host.numpy(), n)
+        self._future = PendingCorrelations._pool.submit(work)
+
+    def done(self) -> bool:
+        return self._future.done()
+
+    def result(self) -> dict:
+        r = self._future.result()
+        self._keep = None
+        return r
+
+
+def compute_correlations_deferred(a: torch.Tensor, b: torch.Tensor, normalize: bool = True) -> PendingCorrelations:
+    """compute_correlations without waiting: device reductions + the copy are enqueued, the host's fit runs on a worker thread."""
+    return PendingCorrelations(*_enqueue_rank_metrics(a, b, normalize))
+
+
+def compute_correlations_cat_flat(ys, yp, num_repeats: int = 1, defer: bool = False):
+    """ys, yp: lists of per-batch device tensors in loop order (train.py:403-409).  defer=True: a PendingCorrelations (the fit on a worker thread)."""
     y = torch.cat([t.detach().reshape(-1).float() for t in ys])
     p = torch.cat([t.detach().reshape(-1).float() for t in yp])
     if num_repeats > 1:
         y, p = average_over_repeats(y, num_repeats), average_over_repeats(p, num_repeats)
-    return compute_correlations(y, p)
+    return compute_correlations_deferred(y, p) if defer else compute_correlations(y, p)
 
 
 def predict_repeats(model, pref_module, datas, is_pairwise: bool, use_scales: bool):
@@ -114,8 +163,10 @@ def predict_repeats(model, pref_module, datas, is_pairwise: bool, use_scales: bo
 
 
 def do_validation(model, pref_module, device, is_pairwise, loader, num_repeats: int = 1, use_scales: bool = False,
-                  output_logger=None, tag: str = "", step: int = 0):
-    """The scoring part of train.do_validation (train.py:583-644): returns (step, correlations or None)."""
+                  output_logger=None, tag: str = "", step: int = 0, defer: bool = False):
+    """The scoring part of train.do_validation (train.py:583-644): returns (step, correlations or None).  defer=True: the correlations come
+    back as a PendingCorrelations -- the set's device reductions are enqueued, its logistic fit runs on a worker thread while the caller
+    starts the next pass; `.result()` gives the dict."""
     y, yp = [], []
     with torch.no_grad():
         model.eval()
@@ -130,5 +181,5 @@ def do_validation(model, pref_module, device, is_pairwise, loader, num_repeats: 
                 if output_logger is not None:                        # the score CSV (train.py:627-632) needs the values now
                     output_logger(i, tag, ",".join(str(v) for v in np.array(q_p.detach().cpu())))
                 step += 1
-    correlations = compute_correlations_cat_flat(y, yp, num_repeats) if y else None
+    correlations = compute_correlations_cat_flat(y, yp, num_repeats, defer=defer) if y else None
     return step, correlations
