@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _libraries_are_current():
+    """Both libraries -- the product's and the fp8 experiment's -- are (re)built from the tree's sources before the first test when they are missing
+    or older than a source (vtamiq_amd.build: a no-op otherwise; hipcc is on the CPU container and on the GPU boxes), so that no test runs against
+    a stale .so.  The tests themselves never build on demand: a missing library is a failure there (no fallback)."""
+    from vtamiq_amd import build
+    build.build(verbose=False)
+    build.build(verbose=False, fp8=True)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

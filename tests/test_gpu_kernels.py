@@ -341,6 +341,53 @@ def test_attention_kernels_agree_bitwise(fmt, nseq, S, H):
                 lib.vtq_debug_attention_variant(-1)
         assert torch.equal(outs[0][:, : nseq * S], outs[1][:, : nseq * S])
         assert torch.equal(outs[0][:, : nseq * S], outs[2][:, : nseq * S])
+    # the pipelined kernel's two block walks (XCD-strided, the default; consecutive / paired, vtq_debug_attention_map(1)) and a grid sized
+    # for fewer CUs (vtq_debug_cu_partition: a CU-masked stream's share) visit the same blocks: the same bits
+    try:
+        lib.vtq_debug_attention_variant(1)
+        ref = _attention_case(lib, fmt, nseq, S, H, True, spike_row=S - 3).view(torch.int16).clone()
+        _lib.check(lib.vtq_debug_attention_map(1))
+        walk = _attention_case(lib, fmt, nseq, S, H, True, spike_row=S - 3).view(torch.int16).clone()
+        _lib.check(lib.vtq_debug_attention_map(0))
+        _lib.check(lib.vtq_debug_cu_partition(0, 64))
+        part = _attention_case(lib, fmt, nseq, S, H, True, spike_row=S - 3).view(torch.int16).clone()
+    finally:
+        lib.vtq_debug_attention_variant(-1)
+        lib.vtq_debug_attention_map(0)
+        lib.vtq_debug_cu_partition(0, 0)
+    assert torch.equal(ref[:, : nseq * S], walk[:, : nseq * S]) and torch.equal(ref[:, : nseq * S], part[:, : nseq * S])
+
+
+def test_cu_partition_hooks():
+    """The measurement hooks behind tools/cu_partition.py: vtq_debug_cu_map reports one distinct CU per CU-filling workgroup on an unmasked stream
+    (XCC id 0 .. 7, 32 each on an MI355X), and a persistent GEMM sized for 24 of the 32 CUs of every XCD (its tile schedule rebuilt for 192
+    workgroups) gives the bits of the full grid."""
+    lib = _lib.load()
+    n = torch.cuda.get_device_properties(0).multi_processor_count
+    out = torch.zeros(2 * n, dtype=torch.int32, device=DEV)
+    _lib.check(lib.vtq_debug_cu_map(out.data_ptr(), n, 300, stream()))
+    torch.cuda.synchronize()
+    v = out.cpu().numpy().astype("uint32").reshape(n, 2)
+    cus = {(int(x) & 15, (int(h) >> 13) & 7, (int(h) >> 12) & 1, (int(h) >> 8) & 15) for x, h in v}
+    assert len(cus) == n and {c[0] for c in cus} == set(range(8))
+    M, N, K, fmt = 4096, 768, 768, "fp16x3"
+    A, W, bias = _randn(M, K, seed=5), _randn(N, K, seed=6, scale=0.03), _randn(N, seed=7)
+    Ap, Wp = to_planes(A, fmt, "a"), to_planes(W, fmt, "w")
+    outs = []
+    try:
+        _lib.check(lib.vtq_debug_gemm_variant(0))              # the persistent 256x256 kernel
+        for g in (0, 24, 20):
+            _lib.check(lib.vtq_debug_cu_partition(g, 0))
+            o = torch.zeros((Ap.shape[0], M, N), dtype=elt_dtype(fmt), device=DEV)
+            _lib.check(lib.vtq_k_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, num_code(fmt), 0, bias.data_ptr(), None, None,
+                                      o.data_ptr(), M * N, N, stream()))
+            torch.cuda.synchronize()
+            outs.append(o.view(torch.int16).clone())
+    finally:
+        lib.vtq_debug_cu_partition(0, 0)
+        lib.vtq_debug_gemm_variant(-1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert lib.vtq_debug_cu_partition(33, 0) != 0 and lib.vtq_debug_attention_map(2) != 0
 
 
 @pytest.mark.parametrize("fmt", ["bf16x3", "bf16"])
