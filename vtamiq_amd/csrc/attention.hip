@@ -460,9 +460,6 @@ struct PPFrags {                      // DIST + 1 rolling fragment buffers: grou
 #ifndef VTQ_SW_QPF
 #define VTQ_SW_QPF 1                  // the next block's Q rows are pulled into L2 two iterations before they are loaded (0: measurement builds)
 #endif
-#ifndef VTQ_SW_DMA_OLD
-#define VTQ_SW_DMA_OLD 0              // measurement builds: 1 = the LDS-DMA of a tile issued by waves 0 - 3 only (their own eighth and their SIMD partner's)
-#endif
 #ifndef VTQ_SW_EARLY_WRITE
 #define VTQ_SW_EARLY_WRITE 1          // a finished block's output is written at the top of the next iteration (0: in its middle, the round-3 place)
 #endif
@@ -659,17 +656,11 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
         if (ib >= b1) return false;
         char* sb = smem + (itau & 3) * STAGE + wave * 1024;
         const T* base = qkv + ibase + (int64_t)it * KT * ld;
-        if (!VTQ_SW_DMA_OLD || wave < 4) {
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                if (VTQ_SW_NODMA) break;
-                glds16(base + pl * plane + k_off, sb + pl * TB);
-                glds16(base + pl * plane + v_off, sb + (NPL + pl) * TB);
-                if (VTQ_SW_DMA_OLD) {                 // the SIMD partner's eighth: rows + 32 of the tile (same swizzle), LDS slice of wave + 4
-                    glds16(base + pl * plane + k_off + 32 * ld, sb + 4096 + pl * TB);
-                    glds16(base + pl * plane + v_off + 32 * ld, sb + 4096 + (NPL + pl) * TB);
-                }
-            }
+        for (int pl = 0; pl < NPL; ++pl) {
+            if (VTQ_SW_NODMA) break;
+            glds16(base + pl * plane + k_off, sb + pl * TB);
+            glds16(base + pl * plane + v_off, sb + (NPL + pl) * TB);
         }
         ++itau;
         if (++it == nt) {
@@ -878,18 +869,11 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
     // planes) when that row is a masked key -- behind the wait that lands the piece, in front of the barrier that publishes the tile.
     const int tail_valid = S - (nt - 1) * KT;
     auto zero_masked_v = [&](int g) __attribute__((always_inline)) {
-        if (d_row >= tail_valid && (!VTQ_SW_DMA_OLD || wave < 4)) {
+        if (d_row >= tail_valid) {
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + (uint32_t)((g & 3) * STAGE + (NPL + pl) * TB + tid * 16)), "v"(z) : "memory");
-            }
-        }
-        if (VTQ_SW_DMA_OLD && wave < 4 && d_row + 32 >= tail_valid) {
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + (uint32_t)((g & 3) * STAGE + (NPL + pl) * TB + (tid + 256) * 16)), "v"(z) : "memory");
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1150,10 +1134,6 @@ __global__ __launch_bounds__(512) void attention_sw_kernel(const T* __restrict__
 #pragma unroll
         for (int d = 0; d < 2; ++d) sA[d] = sB[d];
         VTQ_AT_SPAN(dg_rest);
-        if (VTQ_SW_DMA_OLD && sent) {              // waves 0 - 3 have 2 NI pieces of the newest tile in flight, waves 4 - 7 none
-            if (wave < 4) { if (q_pf_sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(2 * NI + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(2 * NI) : "memory"); }
-            else { if (q_pf_sent) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        } else
         if (sent && q_pf_sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI + 1) : "memory");
         else if (sent) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
