@@ -244,7 +244,7 @@ def test_attention_kernel_rule():
     rule = lambda nseq, S, H, fmt, cus=256: lib.vtq_k_attention_rule(nseq, S, H, _lib.NUM[fmt], cus)
     assert rule(64, 501, 768, "fp16x3") == 1 and rule(64, 501, 768, "bf16x3") == 1          # BASELINE configs[1], B = 32
     assert rule(64, 501, 768, "fp16") == 0 and rule(64, 501, 768, "bf16") == 0              # single-plane formats: 4-wave kernel
-    assert rule(32, 1025, 1024, "fp16x3") == 2                                              # configs[3]: the one row of the 5th block goes to the split form
+    assert rule(32, 1025, 1024, "fp16x3") == 1                                              # configs[3]: five 256-row blocks, the fifth with one active wave (the split form lost, round 6)
     assert rule(8, 2501, 768, "fp16x3") == 1                                                # N = 2500: 960 blocks = 3.75 per CU
     assert rule(2, 257, 768, "fp16x3") == 0 and rule(64, 330, 768, "fp16x3") == 0           # 33 % more padded rows
     assert rule(4, 300, 768, "fp16x3") == 0 and rule(3, 51, 768, "fp16x3") == 0             # grids that leave CUs idle
@@ -252,11 +252,11 @@ def test_attention_kernel_rule():
     assert rule(14, 501, 768, "fp16x3") == 0 and rule(19, 501, 768, "fp16x3") == 1          # 336 of 512 slots: 66 %; 456: 89 %
     assert rule(76, 501, 768, "fp16x3", cus=304) == 1 and rule(64, 501, 768, "fp16x3", cus=304) == 0   # 1824 = 6 x 304; 1536 of 1824 slots: 84 %
     assert rule(64, 501, 768, "fp16x2") == 0 and rule(64, 501, 768, "fp8") in (0, -1)       # no 2-term attention (the fp16x2 ENGINE mode runs fp16x3 attention)
-    # split form (2): the pipelined kernel on the full 256-row blocks + the 4-wave kernel on the <= 64 rows behind them
-    assert rule(32, 521, 768, "fp16x3") == 2 and rule(32, 521, 768, "bf16x3") == 2          # the reference-default topology: 512 patches + 9 tokens, B = 16
-    assert rule(32, 521, 768, "fp16") == 0 and rule(2, 521, 768, "fp16x3") == 0             # single plane; 48 full blocks on 256 CUs
-    assert rule(32, 577, 768, "fp16x3") == 0 and rule(32, 512, 768, "fp16x3") == 1          # 65 rows past 512: not split; no rest at all
-    assert rule(64, 257, 768, "fp16x3") == 2                                                # one row past 256
+    # the split form (2: pipelined kernel on the full 256-row blocks + the 4-wave kernel on the rows behind them) is a measurement form only since round 6
+    assert rule(32, 521, 768, "fp16x3") == 0 and rule(32, 521, 768, "bf16x3") == 0          # the reference-default topology (512 patches + 9 tokens): 768 padded rows against 640
+    assert rule(32, 521, 768, "fp16") == 0 and rule(2, 521, 768, "fp16x3") == 0
+    assert rule(32, 577, 768, "fp16x3") == 0 and rule(32, 512, 768, "fp16x3") == 1
+    assert rule(64, 257, 768, "fp16x3") == 0 and rule(32, 769, 768, "fp16x3") == 1          # one row past 256: 512 padded rows against 384; past 768: 1024 against 896
 
 
 def test_gemm_tile_rule_is_host_only():

@@ -1267,10 +1267,11 @@ int device_cus(int* cus) {
 // persistent grid filled, and no more than 15 % more padded query rows than the 128-row blocks of the 4-wave kernel (waves without rows
 // skip their arithmetic, so padding costs the skeleton only: S = 1025 pads 11 % more rows and is 6 % faster; S = 257 pads 33 % more
 // and is 34 % slower).
-// SPLIT (2): a sequence a few rows longer than a multiple of 256 -- the reference's default topology is 512 patches + CLS + 8 register
-// tokens = 521 -- would pay a whole 256-row (or 128-row) block for those few rows; instead the pipelined kernel takes the full 256-row
-// blocks and ONE launch of the 4-wave kernel the rest (query rows [256 k, S); its waves without rows only stage).  Same arithmetic per
-// query row in every form: outputs are bit-identical (tests/test_gpu_kernels.py).
+// SPLIT (2), a measurement form since round 6: the pipelined kernel on the full 256-row blocks and ONE launch of the 4-wave kernel on the rows behind them
+// (sequences a few rows longer than a multiple of 256: 521 = the reference's default topology, 1025 = configs[3]).  It was the rule's choice in round 5; with
+// the XCD-strided block walk a last block with one active wave costs 0.7 of a block and the rule's own two cases are as fast or faster at every such shape
+// (profiles/r06_attention_loop.txt section 9: S = 1025 -2 .. -5 % against the split form, S = 521 / 545 / 769 within 1 %).  vtq_debug_attention_variant(2) still
+// runs it.  Same arithmetic per query row in every form: outputs are bit-identical (tests/test_gpu_kernels.py).
 int attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
     if (terms != 3 || cus < 1 || nseq < 1 || S_pad < 1 || H % 64) return 0;
     auto fills = [&](int rows) {
@@ -1278,8 +1279,6 @@ int attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
         const int per = (nblk + cus - 1) / cus;
         return (double)nblk >= 0.85 * (double)per * cus;
     };
-    const int full = (S_pad / 256) * 256, rest = S_pad - full;
-    if (full > 0 && rest > 0 && rest <= 64 && fills(full)) return 2;
     const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 115;
     return (fills(S_pad) && rows_ok) ? 1 : 0;
 }
