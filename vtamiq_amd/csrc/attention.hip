@@ -1263,7 +1263,8 @@ int device_cus(int* cus) {
 }
 
 // Which kernel: the pipelined one pays in the 3-term formats (profiles/r03_attention_anatomy.txt: -7 .. -17 % at the encoder's shapes; the
-// single-plane formats are equal or slower), and only when its 256-row blocks keep the CUs busy: at least 85 % of the block slots of the
+// single-plane formats are equal or slower), and only when its 256-row blocks keep the CUs busy: at least 74 % (round 6, sustained timing
+// with the XCD-strided walk: 8 sequences x 501 = 75 % of one round is 11 % faster than the 4-wave kernel, 16 and 24 sequences tie; 85 % before) of the block slots of the
 // persistent grid filled, and no more than 15 % more padded query rows than the 128-row blocks of the 4-wave kernel (waves without rows
 // skip their arithmetic, so padding costs the skeleton only: S = 1025 pads 11 % more rows and is 6 % faster; S = 257 pads 33 % more
 // and is 34 % slower).
@@ -1277,7 +1278,7 @@ int attention_rule(int nseq, int S_pad, int H, int terms, int cus) {
     auto fills = [&](int rows) {
         const int nblk = ((rows + 255) / 256) * (H / 64) * nseq;
         const int per = (nblk + cus - 1) / cus;
-        return (double)nblk >= 0.85 * (double)per * cus;
+        return (double)nblk >= 0.74 * (double)per * cus;
     };
     const bool rows_ok = ((S_pad + 255) / 256) * 256 * 100 <= ((S_pad + 127) / 128) * 128 * 115;
     return (fills(S_pad) && rows_ok) ? 1 : 0;
