@@ -362,32 +362,61 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     float amax8 = 0.f;                      // fp8 mode: max |context value| of this lane's real rows (kernels.h Fp8Obs)
-    if (q_row < S_pad) {
+    if (out8_scale > 0.f) {                 // fp8 mode: the out-proj GEMM reads e4m3 bytes (direct stores, one 64-byte piece per row)
+        if (q_row < S_pad) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dcol = 32 * d + 8 * g4 + 4 * hh;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
+                    if (q_row < S) amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
+                    *(uint32_t*)((uint8_t*)out + (row0 + q_row) * H + head * 64 + dcol) =
+                        pack_fp8x4(v[0] * out8_scale, v[1] * out8_scale, v[2] * out8_scale, v[3] * out8_scale);
+                }
+        }
+    } else if constexpr (NSPLIT == 1) {
+        // Single plane: staged through LDS (the K / V buffers are free: the loop ended with a barrier), as the pipelined kernel does -- each wave transposes
+        // its 32 rows x 128 bytes through its own 4 KB image (chunk index XORed with row & 7), so that every store instruction writes eight whole 128-byte
+        // row segments, 16 B per lane, instead of 32 pieces of 8 B at the row stride.  Same values.  Inside a forward (fp16 mode, B = 32) 89.5 -> 83.3 us;
+        // the two-plane formats keep the direct stores below (staged: S = 521 +2 %, S = 1025 +3 %; profiles/r06_attention_loop.txt section 11).
+        if (wave_active) {
+            char* const o_stage = smem + wave * 4096;
+            const int r_row = lane >> 3, r_chunk = lane & 7;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                         // chunk k = 4 d + g4 of row c, bytes 8 hh .. 8 hh + 7
+                tx4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = o_acc[k >> 2][4 * (k & 3) + e] * inv;
+                    asm volatile("" : "+v"(v));                   // rounded product, then converted (no fused form)
+                    hv[e] = (T)v;
+                }
+                *(tx4*)(o_stage + c * 128 + ((k ^ (c & 7)) << 4) + 8 * hh) = hv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r_row + 8 * k;
+                const uint4 w = *(const uint4*)(o_stage + row * 128 + ((r_chunk ^ (row & 7)) << 4));
+                const int qr = q0 + qb * 128 + wave * 32 + row;
+                if (qr < S_pad) *(uint4*)(out + (row0 + qr) * H + head * 64 + 8 * r_chunk) = w;
+            }
+        }
+    } else if (q_row < S_pad) {
         T* o = out + (row0 + q_row) * H + head * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int dcol = 32 * d + 8 * g4 + 4 * hh;
-                float v[4];
+                tx4 hv, lv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = o_acc[d][4 * g4 + e] * inv;
-                if (out8_scale > 0.f) {          // fp8 mode: the out-proj GEMM reads e4m3 bytes
-                    if (q_row < S) amax8 = amax4(amax8, v[0], v[1], v[2], v[3]);
-                    *(uint32_t*)((uint8_t*)out + (row0 + q_row) * H + head * 64 + dcol) =
-                        pack_fp8x4(v[0] * out8_scale, v[1] * out8_scale, v[2] * out8_scale, v[3] * out8_scale);
-                } else if constexpr (NSPLIT == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));        // rounded product, then converted (no fused form)
-                    tx4 hv = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                    *(tx4*)(o + dcol) = hv;
-                } else {
-                    tx4 hv, lv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { T a, b; split2<T>(v[e], a, b); hv[e] = a; lv[e] = b; }
-                    *(tx4*)(o + dcol) = hv;
-                    *(tx4*)(o + o_plane + dcol) = lv;
-                }
+                for (int e = 0; e < 4; ++e) { T a, b; split2<T>(o_acc[d][4 * g4 + e] * inv, a, b); hv[e] = a; lv[e] = b; }
+                *(tx4*)(o + dcol) = hv;
+                *(tx4*)(o + o_plane + dcol) = lv;
             }
     }
     if (out8_scale > 0.f) fp8_report(obs, amax8, out8_scale);
